@@ -1,0 +1,130 @@
+/*
+ * warp_rnnt_amd.h -- C ABI of the MI355X-native RNN-Transducer loss
+ * (libwarp_rnnt_amd.so).  Plain pointers and sizes only; every pointer is a
+ * DEVICE pointer unless stated otherwise; every call only ENQUEUES work on
+ * `stream` (no allocation, no host synchronisation, no global state), so the
+ * library is re-entrant across streams and threads.
+ *
+ * Part 1 mirrors the reference's own C interface for this path
+ * (1ytic/warp-rnnt core.h) so that the reference's bindings can link against
+ * this library unchanged.  Part 2 is the native interface
+ * the bundled Python host (warp_rnnt/_C.py) uses: it adds a caller-provided
+ * workspace so the lattice kernels can run on the diagonal-major layout.
+ */
+#ifndef WARP_RNNT_AMD_H
+#define WARP_RNNT_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* HIP's stream handle (hip_runtime_api.h: typedef struct ihipStream_t* hipStream_t). */
+typedef struct ihipStream_t *rnntStream_t;
+
+/* Replaces core.h:16-22.  Codes 0-4 keep the reference's numbering; because the two
+ * gradient kernels and the cost kernel are one fused launch here, a failure of that
+ * launch is reported as 2 and codes 3/4 are never produced.  5-7 are new. */
+typedef enum {
+    RNNT_STATUS_SUCCESS = 0,
+    RNNT_STATUS_WARP_FAILED = 1,         /* alpha/beta lattice launch failed */
+    RNNT_STATUS_GRADS_BLANK_FAILED = 2,  /* fused gradient+cost launch failed */
+    RNNT_STATUS_GRADS_LABEL_FAILED = 3,
+    RNNT_STATUS_COSTS_FAILED = 4,
+    RNNT_STATUS_INVALID_ARGUMENT = 5,    /* rejected before any launch */
+    RNNT_STATUS_PROLOGUE_FAILED = 6,     /* log-softmax / gather / re-layout launch failed */
+    RNNT_STATUS_EXPAND_FAILED = 7        /* dense gradient expansion launch failed */
+} rnntStatus_t;
+
+/* ------------------------------------------------------------------------
+ * Part 1 -- drop-in for the reference C interface
+ * ------------------------------------------------------------------------ */
+
+/*
+ * Replaces run_warp_rnnt (core.h:29-33, core.cu:372-401): dense layout.
+ *   log_probs (N,T,U,V) fp32, labels (N,U-1) int32, xn/yn (N,) int32.
+ *   grads (N,T,U,V): MUST be zeroed by the caller (as binding.cpp:58 does); only
+ *     the blank/label slots of live cells are written.
+ *   counts (N,2U) uint32, alphas/betas (N,T,U) fp32: caller scratch, contents on
+ *     return unspecified (alphas/betas hold the lattices in diagonal-major order,
+ *     counts[n*2U] holds the alpha-side log-likelihood bits).  counts need not be zeroed.
+ *   costs (N,): out.
+ */
+rnntStatus_t run_warp_rnnt(rnntStream_t stream, unsigned int *counts, float *alphas, float *betas,
+                           const int *labels, const float *log_probs, float *grads, float *costs,
+                           const int *xn, const int *yn, int N, int T, int U, int V, int blank,
+                           float fastemit_lambda);
+
+/*
+ * Replaces run_warp_rnnt_gather (core.h:35-39, core_gather.cu:359-388): gathered layout,
+ *   log_probs and grads (N,T,U,2) with channel 0 = blank, channel 1 = label.
+ *   grads is fully written (zeros included); pre-zeroing is allowed but not needed.
+ */
+rnntStatus_t run_warp_rnnt_gather(rnntStream_t stream, unsigned int *counts, float *alphas,
+                                  float *betas, const float *log_probs, float *grads, float *costs,
+                                  const int *xn, const int *yn, int N, int T, int U,
+                                  float fastemit_lambda);
+
+/* ------------------------------------------------------------------------
+ * Part 2 -- native interface (workspace-based, diagonal-major lattice layout)
+ * ------------------------------------------------------------------------ */
+
+/* what `input` holds */
+enum {
+    RNNT_IN_LOG_PROBS_DENSE = 0,    /* (N,T,U,V) log-probabilities + labels       */
+    RNNT_IN_LOG_PROBS_GATHERED = 1, /* (N,T,U,2) blank/label log-probabilities    */
+    RNNT_IN_LOGITS_DENSE = 2        /* (N,T,U,V) unnormalised logits + labels: log-softmax
+                                       and gather are fused, log-probs never materialise */
+};
+/* what `grads` receives (always d cost[n] / d log_probs, FastEmit included) */
+enum {
+    RNNT_GRADS_GATHERED = 0,        /* (N,T,U,2) row-major, fully written          */
+    RNNT_GRADS_GATHERED_DIAGONAL = 1, /* (N,T,U,2) diagonal-major, fully written; opaque, feed to
+                                       rnnt_amd_expand_grads                        */
+    RNNT_GRADS_DENSE = 2,           /* (N,T,U,V) row-major, fully written (no pre-zeroing)  */
+    RNNT_GRADS_NONE = 3             /* costs only                                   */
+};
+
+/* Bytes of device scratch rnnt_amd_loss needs for a problem of this size. */
+size_t rnnt_amd_workspace_size(int N, int T, int U);
+
+/*
+ * The loss: costs (N,) and gradients in one call.
+ *   workspace: >= rnnt_amd_workspace_size(N,T,U) bytes, 256-byte aligned, contents unspecified.
+ *   labels may be NULL for RNNT_IN_LOG_PROBS_GATHERED or when U == 1.
+ *   V/blank are ignored for RNNT_IN_LOG_PROBS_GATHERED.
+ *   RNNT_GRADS_DENSE is available for RNNT_IN_LOG_PROBS_DENSE only.
+ */
+rnntStatus_t rnnt_amd_loss(rnntStream_t stream, void *workspace, int input_kind, const float *input,
+                           const int *labels, const int *xn, const int *yn, float *costs, float *grads,
+                           int grads_kind, int N, int T, int U, int V, int blank,
+                           float fastemit_lambda);
+
+/*
+ * Backward of the gather prologue (warp_rnnt/__init__.py:21-24,126): expands
+ * RNNT_GRADS_GATHERED_DIAGONAL gradients, scaled by grad_costs[n] (NULL = 1), into a dense
+ * (N,T,U,V) tensor that is fully written.  overwrite != 0 selects the dense kernels'
+ * "label slot overwrites blank slot" rule instead of scatter-add.
+ */
+rnntStatus_t rnnt_amd_expand_grads(rnntStream_t stream, const float *grads_diagonal, const int *labels,
+                                   const int *xn, const int *yn, const float *grad_costs,
+                                   float *dense_grads, int N, int T, int U, int V, int blank,
+                                   int overwrite);
+
+/* Row-wise log-softmax over the last axis; out may alias x. */
+rnntStatus_t rnnt_amd_log_softmax(rnntStream_t stream, const float *x, float *out, int64_t rows, int V);
+
+/* (N,T,U,V) log-probs -> (N,T,U,2) row-major gathered log-probs (the tensor the reference's
+ * wrapper hands to the native op, __init__.py:122-126).  `workspace` as for rnnt_amd_loss. */
+rnntStatus_t rnnt_amd_gather(rnntStream_t stream, const float *log_probs, const int *labels,
+                             float *gathered, int N, int T, int U, int V, int blank);
+
+/* Library version, for the host-side loader. */
+int rnnt_amd_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WARP_RNNT_AMD_H */

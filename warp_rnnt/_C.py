@@ -1,0 +1,75 @@
+"""Native-op module of the drop-in package: same functions, keyword names, check order and
+error texts as the reference's pybind module ``warp_rnnt._C``
+(pytorch_binding/binding.cpp:28-106, 249-254), implemented on the C ABI of
+libwarp_rnnt_amd.so through ctypes.  There is no CPU path: tensors must live on a GPU
+("CUDA" device type under PyTorch-ROCm) and the HIP library must be built.
+"""
+import torch
+
+from warp_rnnt_amd import ops as _ops
+
+
+def _check_contiguous(x, name):
+    if not x.is_contiguous():
+        raise RuntimeError(f"{name} must be contiguous")
+
+
+def _check_float(x, name):
+    if x.dtype != torch.float32:
+        raise RuntimeError(f"{name} must be a Float tensor")
+
+
+def _check_int(x, name):
+    if x.dtype != torch.int32:
+        raise RuntimeError(f"{name} must be a Int tensor")
+
+
+def _check_cuda(x, name):
+    if x.device.type != "cuda":
+        raise RuntimeError(f"{name} must be located in the CUDA")
+
+
+def check_inputs(xs, ys, xn, yn):
+    """binding.cpp:32-51 -- contiguity, then dtypes, then device, then shapes."""
+    for x, name in ((xs, "xs"), (ys, "ys"), (xn, "xn"), (yn, "yn")):
+        _check_contiguous(x, name)
+    _check_float(xs, "xs")
+    for x, name in ((ys, "ys"), (xn, "xn"), (yn, "yn")):
+        _check_int(x, name)
+    for x, name in ((xs, "xs"), (ys, "ys"), (xn, "xn"), (yn, "yn")):
+        _check_cuda(x, name)
+    if xs.dim() != 4:
+        raise RuntimeError("xs must have 4 dimensions")
+    if xn.numel() != xs.size(0):
+        raise RuntimeError("xn shape must be equal (N,)")
+    if yn.numel() != xs.size(0):
+        raise RuntimeError("yn shape must be equal (N,)")
+    if ys.dim() != 2 or xs.size(2) != ys.size(1) + 1:
+        raise RuntimeError("ys shape (N, U-1) mismatched with xs (N, T, U, V)")
+    for x, name in ((ys, "ys"), (xn, "xn"), (yn, "yn")):
+        if x.device != xs.device:
+            raise RuntimeError(f"{name} must be on the same device as xs")
+
+
+def rnnt_loss(xs, ys, xn, yn, blank=0, fastemit_lambda=0.0):
+    """(costs (N,), grads like xs).  blank == -1 selects the gathered (N,T,U,2) layout."""
+    check_inputs(xs, ys, xn, yn)
+    if blank == -1:
+        if xs.size(3) != 2:
+            raise RuntimeError("xs must have values only for blank and label")
+        return _ops.loss(xs, None, xn, yn, _ops.IN_LOG_PROBS_GATHERED, _ops.GRADS_GATHERED,
+                         0, fastemit_lambda)
+    return _ops.loss(xs, ys, xn, yn, _ops.IN_LOG_PROBS_DENSE, _ops.GRADS_DENSE, blank, fastemit_lambda)
+
+
+def rnnt_loss_gather(xs, ys, xn, yn, blank=0, fastemit_lambda=0.0):
+    """Native form of the wrapper's ``gather=True`` branch: dense log-probs in, costs and the
+    (opaque, diagonal-major) gathered gradients out; feed those to :func:`rnnt_loss_gather_backward`."""
+    check_inputs(xs, ys, xn, yn)
+    return _ops.loss(xs, ys, xn, yn, _ops.IN_LOG_PROBS_DENSE, _ops.GRADS_GATHERED_DIAGONAL,
+                     blank, fastemit_lambda)
+
+
+def rnnt_loss_gather_backward(grad_costs, grads_diagonal, ys, xn, yn, V, blank=0):
+    """d loss / d log_probs (N,T,U,V) = scatter-add of the gathered grads times grad_costs[n]."""
+    return _ops.expand_grads(grads_diagonal, ys, xn, yn, grad_costs, V, blank, overwrite=False)

@@ -1,0 +1,64 @@
+"""ctypes binding of the C ABI in include/warp_rnnt_amd.h.
+
+Import torch before calling :func:`load` in a process that also uses torch:
+the library depends on ``libamdhip64.so.7`` and must share the HIP runtime
+torch already loaded (same SONAME, so the dynamic loader reuses it), otherwise
+stream handles would belong to a different runtime.
+"""
+import ctypes
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_NAME = "libwarp_rnnt_amd.so"
+_lib = None
+
+STATUS_NAMES = {
+    0: "RNNT_STATUS_SUCCESS", 1: "RNNT_STATUS_WARP_FAILED", 2: "RNNT_STATUS_GRADS_BLANK_FAILED",
+    3: "RNNT_STATUS_GRADS_LABEL_FAILED", 4: "RNNT_STATUS_COSTS_FAILED",
+    5: "RNNT_STATUS_INVALID_ARGUMENT", 6: "RNNT_STATUS_PROLOGUE_FAILED", 7: "RNNT_STATUS_EXPAND_FAILED",
+}
+
+# input_kind / grads_kind enums of rnnt_amd_loss
+IN_LOG_PROBS_DENSE, IN_LOG_PROBS_GATHERED, IN_LOGITS_DENSE = 0, 1, 2
+GRADS_GATHERED, GRADS_GATHERED_DIAGONAL, GRADS_DENSE, GRADS_NONE = 0, 1, 2, 3
+
+# every symbol include/warp_rnnt_amd.h declares: (restype, argtypes)
+_vp, _i, _f, _sz, _i64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t, ctypes.c_int64
+SYMBOLS = {
+    "run_warp_rnnt": (_i, [_vp] * 10 + [_i] * 5 + [_f]),
+    "run_warp_rnnt_gather": (_i, [_vp] * 9 + [_i] * 3 + [_f]),
+    "rnnt_amd_workspace_size": (_sz, [_i, _i, _i]),
+    "rnnt_amd_loss": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f]),
+    "rnnt_amd_expand_grads": (_i, [_vp] * 7 + [_i] * 6),
+    "rnnt_amd_log_softmax": (_i, [_vp, _vp, _vp, _i64, _i]),
+    "rnnt_amd_gather": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i]),
+    "rnnt_amd_version": (_i, []),
+}
+
+
+class RNNTStatusError(RuntimeError):
+    pass
+
+
+def lib_path():
+    return os.path.join(HERE, _LIB_NAME)
+
+
+def load():
+    """Load libwarp_rnnt_amd.so; fail loudly if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = lib_path()
+    if not os.path.exists(path):
+        raise RuntimeError(
+            f"{path} is missing: the HIP extension has not been built. Run "
+            "`python -c 'import __graft_entry__ as g; g.build()'` (or `python warp_rnnt_amd/_build.py`). "
+            "There is no CPU fallback.")
+    L = ctypes.CDLL(path)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(L, name)   # AttributeError if the library does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = L
+    return L

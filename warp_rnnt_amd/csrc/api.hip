@@ -1,0 +1,170 @@
+// C ABI of libwarp_rnnt_amd.so (declared in include/warp_rnnt_amd.h).
+// Host-side orchestration only: argument checks, workspace carving, launches.
+#include "../../include/warp_rnnt_amd.h"
+
+#include "common.h"
+#include "kernels.h"
+
+using namespace rnnt;
+
+namespace {
+
+constexpr size_t ALIGN = 256;
+inline size_t align_up(size_t x) { return (x + ALIGN - 1) / ALIGN * ALIGN; }
+
+struct Workspace {
+    float* alphas;
+    float* betas;
+    float* ws2;      // diagonal-major (blank,label) pairs; later the gathered grads
+    float* ll;
+    int* mismatch;
+};
+
+size_t carve(void* base, int N, int T, int U, Workspace* w) {
+    const size_t cells = (size_t)N * T * U;
+    size_t off = 0;
+    char* p = static_cast<char*>(base);
+    auto take = [&](size_t bytes) { size_t o = off; off += align_up(bytes); return p ? p + o : nullptr; };
+    float* alphas = reinterpret_cast<float*>(take(cells * sizeof(float)));
+    float* betas = reinterpret_cast<float*>(take(cells * sizeof(float)));
+    float* ws2 = reinterpret_cast<float*>(take(cells * 2 * sizeof(float)));
+    float* ll = reinterpret_cast<float*>(take((size_t)N * sizeof(float)));
+    int* mismatch = reinterpret_cast<int*>(take((size_t)N * sizeof(int)));
+    if (w) *w = Workspace{alphas, betas, ws2, ll, mismatch};
+    return off;
+}
+
+bool dims_ok(int N, int T, int U) {
+    if (N < 0 || T < 1 || U < 1) return false;
+    if (N > 65535) return false;                               // gridDim.y of the gradient kernel
+    if ((int64_t)T * U >= (int64_t)1 << 31) return false;      // per-utterance cell index is 32-bit
+    return true;
+}
+
+}  // namespace
+
+extern "C" {
+
+int rnnt_amd_version(void) { return 100; }
+
+size_t rnnt_amd_workspace_size(int N, int T, int U) {
+    if (!dims_ok(N, T, U)) return 0;
+    return carve(nullptr, N, T, U, nullptr);
+}
+
+rnntStatus_t run_warp_rnnt(rnntStream_t stream, unsigned int* counts, float* alphas, float* betas,
+                           const int* labels, const float* log_probs, float* grads, float* costs,
+                           const int* xn, const int* yn, int N, int T, int U, int V, int blank,
+                           float fastemit_lambda) {
+    if (!dims_ok(N, T, U) || V < 1 || blank < 0 || blank >= V) return RNNT_STATUS_INVALID_ARGUMENT;
+    if (N == 0) return RNNT_STATUS_SUCCESS;
+    float* ll = reinterpret_cast<float*>(counts);   // (N,2U) uint32 scratch: first N words reused
+    LatticeArgs la{log_probs, labels, xn, yn, alphas, betas, ll, T, U, V, blank};
+    if (launch_lattice(stream, la, N, LOAD_DENSE) != hipSuccess) return RNNT_STATUS_WARP_FAILED;
+    GradArgs ga{log_probs, labels, xn, yn, alphas, betas, ll, grads, costs, nullptr,
+                T, U, V, blank, fastemit_lambda};
+    if (launch_grads(stream, ga, N, LOAD_DENSE, WRITE_DENSE_SLOTS) != hipSuccess)
+        return RNNT_STATUS_GRADS_BLANK_FAILED;
+    return RNNT_STATUS_SUCCESS;
+}
+
+rnntStatus_t run_warp_rnnt_gather(rnntStream_t stream, unsigned int* counts, float* alphas,
+                                  float* betas, const float* log_probs, float* grads, float* costs,
+                                  const int* xn, const int* yn, int N, int T, int U,
+                                  float fastemit_lambda) {
+    if (!dims_ok(N, T, U)) return RNNT_STATUS_INVALID_ARGUMENT;
+    if (N == 0) return RNNT_STATUS_SUCCESS;
+    float* ll = reinterpret_cast<float*>(counts);
+    LatticeArgs la{log_probs, nullptr, xn, yn, alphas, betas, ll, T, U, 2, 0};
+    if (launch_lattice(stream, la, N, LOAD_ROWMAJOR2) != hipSuccess) return RNNT_STATUS_WARP_FAILED;
+    GradArgs ga{log_probs, nullptr, xn, yn, alphas, betas, ll, grads, costs, nullptr,
+                T, U, 2, 0, fastemit_lambda};
+    if (launch_grads(stream, ga, N, LOAD_ROWMAJOR2, WRITE_ROWMAJOR2) != hipSuccess)
+        return RNNT_STATUS_GRADS_BLANK_FAILED;
+    return RNNT_STATUS_SUCCESS;
+}
+
+rnntStatus_t rnnt_amd_loss(rnntStream_t stream, void* workspace, int input_kind, const float* input,
+                           const int* labels, const int* xn, const int* yn, float* costs, float* grads,
+                           int grads_kind, int N, int T, int U, int V, int blank,
+                           float fastemit_lambda) {
+    if (!dims_ok(N, T, U) || !workspace) return RNNT_STATUS_INVALID_ARGUMENT;
+    if (reinterpret_cast<uintptr_t>(workspace) % ALIGN) return RNNT_STATUS_INVALID_ARGUMENT;
+    const bool gathered_in = input_kind == RNNT_IN_LOG_PROBS_GATHERED;
+    if (!gathered_in) {
+        if (V < 1 || blank < 0 || blank >= V) return RNNT_STATUS_INVALID_ARGUMENT;
+        if (U > 1 && !labels) return RNNT_STATUS_INVALID_ARGUMENT;
+    }
+    if (grads_kind == RNNT_GRADS_DENSE && input_kind != RNNT_IN_LOG_PROBS_DENSE)
+        return RNNT_STATUS_INVALID_ARGUMENT;
+    if (grads_kind < RNNT_GRADS_GATHERED || grads_kind > RNNT_GRADS_NONE)
+        return RNNT_STATUS_INVALID_ARGUMENT;
+    if (grads_kind != RNNT_GRADS_NONE && !grads) return RNNT_STATUS_INVALID_ARGUMENT;
+    if (N == 0) return RNNT_STATUS_SUCCESS;
+
+    Workspace w;
+    carve(workspace, N, T, U, &w);
+
+    // 1. bring the (blank,label) log-prob pairs into the diagonal-major workspace
+    hipError_t e;
+    switch (input_kind) {
+        case RNNT_IN_LOG_PROBS_DENSE:
+            e = launch_gather(stream, input, labels, w.ws2, N, T, U, V, blank, true); break;
+        case RNNT_IN_LOG_PROBS_GATHERED:
+            e = launch_reskew(stream, input, w.ws2, N, T, U); break;
+        case RNNT_IN_LOGITS_DENSE:
+            e = launch_log_softmax_gather_skewed(stream, input, labels, w.ws2, N, T, U, V, blank); break;
+        default:
+            return RNNT_STATUS_INVALID_ARGUMENT;
+    }
+    if (e != hipSuccess) return RNNT_STATUS_PROLOGUE_FAILED;
+
+    // 2. alpha / beta sweeps (2N workgroups, concurrent)
+    LatticeArgs la{w.ws2, nullptr, xn, yn, w.alphas, w.betas, w.ll, T, U, 2, 0};
+    if (launch_lattice(stream, la, N, LOAD_SKEWED) != hipSuccess) return RNNT_STATUS_WARP_FAILED;
+
+    // 3. gradients + costs (+ guard).  For a dense result the pairs are produced in place in the
+    //    workspace and expanded to full rows (zeros included) in one coalesced pass.
+    float* gout = grads;
+    int writer = WRITE_ROWMAJOR2;
+    if (grads_kind == RNNT_GRADS_GATHERED_DIAGONAL) writer = WRITE_SKEWED2;
+    if (grads_kind == RNNT_GRADS_DENSE || grads_kind == RNNT_GRADS_NONE) { gout = w.ws2; writer = WRITE_SKEWED2; }
+    GradArgs ga{w.ws2, nullptr, xn, yn, w.alphas, w.betas, w.ll, gout, costs, w.mismatch,
+                T, U, 2, 0, fastemit_lambda};
+    if (launch_grads(stream, ga, N, LOAD_SKEWED, writer) != hipSuccess)
+        return RNNT_STATUS_GRADS_BLANK_FAILED;
+    if (grads_kind == RNNT_GRADS_DENSE) {
+        if (launch_expand(stream, w.ws2, labels, xn, yn, nullptr, grads, N, T, U, V, blank, 1) != hipSuccess)
+            return RNNT_STATUS_EXPAND_FAILED;
+    }
+    return RNNT_STATUS_SUCCESS;
+}
+
+rnntStatus_t rnnt_amd_expand_grads(rnntStream_t stream, const float* grads_diagonal, const int* labels,
+                                   const int* xn, const int* yn, const float* grad_costs,
+                                   float* dense_grads, int N, int T, int U, int V, int blank,
+                                   int overwrite) {
+    if (!dims_ok(N, T, U) || V < 1 || blank < 0 || blank >= V) return RNNT_STATUS_INVALID_ARGUMENT;
+    if ((int64_t)U * V >= (int64_t)1 << 31) return RNNT_STATUS_INVALID_ARGUMENT;
+    if ((int64_t)N * T >= (int64_t)1 << 31) return RNNT_STATUS_INVALID_ARGUMENT;
+    if (launch_expand(stream, grads_diagonal, labels, xn, yn, grad_costs, dense_grads, N, T, U, V, blank,
+                      overwrite) != hipSuccess)
+        return RNNT_STATUS_EXPAND_FAILED;
+    return RNNT_STATUS_SUCCESS;
+}
+
+rnntStatus_t rnnt_amd_log_softmax(rnntStream_t stream, const float* x, float* out, int64_t rows, int V) {
+    if (rows < 0 || V < 1) return RNNT_STATUS_INVALID_ARGUMENT;
+    if (launch_log_softmax(stream, x, out, rows, V) != hipSuccess) return RNNT_STATUS_PROLOGUE_FAILED;
+    return RNNT_STATUS_SUCCESS;
+}
+
+rnntStatus_t rnnt_amd_gather(rnntStream_t stream, const float* log_probs, const int* labels,
+                             float* gathered, int N, int T, int U, int V, int blank) {
+    if (!dims_ok(N, T, U) || V < 1 || blank < 0 || blank >= V) return RNNT_STATUS_INVALID_ARGUMENT;
+    if (launch_gather(stream, log_probs, labels, gathered, N, T, U, V, blank, false) != hipSuccess)
+        return RNNT_STATUS_PROLOGUE_FAILED;
+    return RNNT_STATUS_SUCCESS;
+}
+
+}  // extern "C"

@@ -1,0 +1,114 @@
+// Gradients of the RNN-T cost w.r.t. the log-probabilities + per-utterance costs.
+//
+// Maths (reference: core_gather.cu:248-284 blank, :286-319 label + FastEmit,
+// :321-357 cost and forward/backward guard; dense write order core.cu:382-393):
+//   gB[t,u] = -exp((alpha[t,u] + beta[t+1,u]) + lpB[t,u] - beta[0,0])     t <  T_n-1
+//   gB[T_n-1,U_n-1] = -exp(alpha + lpB - beta[0,0]);  other cells of the last frame: 0
+//   gL[t,u] = -(float)((1.0 + lambda) * exp((alpha[t,u] + beta[t,u+1]) + lpL[t,u] - beta[0,0])),  u < U_n-1
+//   cost[n] = -beta[0,0]   (guard: if alpha-side and beta-side log-likelihoods differ by
+//                           more than 1e-3 relative, grads of the sample are zeroed and the
+//                           cost is the mean of the two, like the reference)
+//
+// One fused element-wise kernel (the reference uses three launches with lanes
+// along t).  Threads walk the lattice in diagonal-major order, so alpha,
+// beta[t+1,u], beta[t,u+1] (= next diagonal, columns u and u+1) and the
+// workspace log-probs are all coalesced row reads.
+#include "common.h"
+#include "kernels.h"
+
+namespace rnnt {
+
+template <int LOADER, int WRITER>
+__global__ void __launch_bounds__(256) k_grads(const GradArgs a) {
+    const int T = a.T, U = a.U;
+    const int n = blockIdx.y;
+    const int Tn = a.xn[n], Un = a.yn[n] + 1;
+    const size_t nb = (size_t)n * T * U;
+    const float* __restrict__ al = a.alphas + nb;
+    const float* __restrict__ be = a.betas + nb;
+
+    const unsigned idx = blockIdx.x * 256u + threadIdx.x;
+    const bool in = idx < (unsigned)(T * U);
+
+    // ---- per-utterance scalars: beta[0,0], alpha-side log-likelihood, guard ----
+    const float b00 = be[0];   // sk(0,0) = 0
+    const float ll_a = a.ll[n];   // alpha[T-1,U-1] + lpB[T-1,U-1], written by the alpha sweep
+    const float ratio = fabsf(ll_a - b00) / fabsf(fmaxf(ll_a, b00));
+    const bool bad = ratio > 0.001f;
+    if (idx == 0) {
+        a.costs[n] = bad ? -((ll_a + b00) / 2.0f) : -b00;
+        if (a.mismatch) a.mismatch[n] = bad ? 1 : 0;
+    }
+    if (!in) return;
+
+    const int r = idx / (unsigned)U;
+    const int u = idx - r * U;
+    int t = (r - u) % T;
+    if (t < 0) t += T;
+    const bool valid = (t < Tn) && (u < Un);
+
+    float gB = 0.0f, gL = 0.0f;
+    if (valid && !bad) {
+        float lpB, lpL;
+        if constexpr (LOADER == LOAD_SKEWED) {
+            const float2 v = reinterpret_cast<const float2*>(a.lp)[nb + idx];
+            lpB = v.x; lpL = v.y;
+        } else if constexpr (LOADER == LOAD_ROWMAJOR2) {
+            const float2 v = reinterpret_cast<const float2*>(a.lp)[nb + (size_t)t * U + u];
+            lpB = v.x; lpL = v.y;
+        } else {
+            const float* p = a.lp + (nb + (size_t)t * U + u) * (size_t)a.V;
+            lpB = p[a.blank];
+            lpL = (u < Un - 1) ? p[a.labels[(size_t)n * (U - 1) + u]] : 0.0f;
+        }
+        const float alpha = al[idx];
+        const int r1 = (r + 1 == T) ? 0 : r + 1;
+        if (t < Tn - 1) {
+            const float x = alpha + be[(size_t)r1 * U + u];
+            gB = -expf(x + lpB - b00);
+        } else if (u == Un - 1) {
+            gB = -expf(alpha + lpB - b00);
+        }
+        if (u < Un - 1) {
+            const float x = alpha + be[(size_t)r1 * U + u + 1];
+            const float e = expf(x + lpL - b00);
+            gL = -(float)((1. + a.fastemit_lambda) * e);
+        }
+    }
+
+    if constexpr (WRITER == WRITE_SKEWED2) {
+        reinterpret_cast<float2*>(a.grads)[nb + idx] = make_float2(gB, gL);
+    } else if constexpr (WRITER == WRITE_ROWMAJOR2) {
+        reinterpret_cast<float2*>(a.grads)[nb + (size_t)t * U + u] = make_float2(gB, gL);
+    } else {
+        // reference C-ABI contract: grads pre-zeroed by the caller, only live slots are written;
+        // blank first, label second (a label equal to blank overwrites, core.cu:382-393)
+        if (valid) {
+            float* g = a.grads + (nb + (size_t)t * U + u) * (size_t)a.V;
+            if (t < Tn - 1 || u == Un - 1) g[a.blank] = gB;
+            if (u < Un - 1) g[a.labels[(size_t)n * (U - 1) + u]] = gL;
+        }
+    }
+}
+
+template <int LOADER>
+static hipError_t launch_grads_w(hipStream_t stream, const GradArgs& a, dim3 grid, int writer) {
+    switch (writer) {
+        case WRITE_SKEWED2:   k_grads<LOADER, WRITE_SKEWED2><<<grid, 256, 0, stream>>>(a); break;
+        case WRITE_ROWMAJOR2: k_grads<LOADER, WRITE_ROWMAJOR2><<<grid, 256, 0, stream>>>(a); break;
+        default:              k_grads<LOADER, WRITE_DENSE_SLOTS><<<grid, 256, 0, stream>>>(a); break;
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_grads(hipStream_t stream, const GradArgs& a, int N, int loader, int writer) {
+    if (N <= 0) return hipSuccess;
+    const dim3 grid(((unsigned)(a.T * a.U) + 255u) / 256u, (unsigned)N);
+    switch (loader) {
+        case LOAD_SKEWED:    return launch_grads_w<LOAD_SKEWED>(stream, a, grid, writer);
+        case LOAD_ROWMAJOR2: return launch_grads_w<LOAD_ROWMAJOR2>(stream, a, grid, writer);
+        default:             return launch_grads_w<LOAD_DENSE>(stream, a, grid, writer);
+    }
+}
+
+}  // namespace rnnt

@@ -1,0 +1,48 @@
+// Internal launch interface between the C ABI (api.hip) and the kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace rnnt {
+
+struct LatticeArgs {
+    const float* lp;      // log-probs in the layout named by the loader
+    const int* labels;    // (N,U-1), LOAD_DENSE only
+    const int* xn;        // (N,) frames per utterance
+    const int* yn;        // (N,) labels per utterance
+    float* alphas;        // (N,T,U) diagonal-major scratch (out)
+    float* betas;         // (N,T,U) diagonal-major scratch (out)
+    float* ll;            // (N,) alpha-side log-likelihood alpha[T-1,U-1]+lpB[T-1,U-1] (out)
+    int T, U, V, blank;   // V/blank: LOAD_DENSE only
+};
+
+struct GradArgs {
+    const float* lp;      // as LatticeArgs
+    const int* labels;
+    const int* xn;
+    const int* yn;
+    const float* alphas;  // diagonal-major
+    const float* betas;   // diagonal-major
+    const float* ll;      // (N,) from the lattice kernel
+    float* grads;         // layout named by the writer
+    float* costs;         // (N,)
+    int* mismatch;        // (N,) optional: 1 where the alpha/beta guard fired
+    int T, U, V, blank;
+    float fastemit_lambda;
+};
+
+hipError_t launch_lattice(hipStream_t stream, const LatticeArgs& a, int N, int loader);
+hipError_t launch_grads(hipStream_t stream, const GradArgs& a, int N, int loader, int writer);
+
+// prologue / epilogue streaming kernels
+hipError_t launch_log_softmax(hipStream_t stream, const float* x, float* out, int64_t rows, int V);
+hipError_t launch_gather(hipStream_t stream, const float* log_probs, const int* labels, float* out2,
+                         int N, int T, int U, int V, int blank, bool skewed);
+hipError_t launch_reskew(hipStream_t stream, const float* lp2_rowmajor, float* ws2, int N, int T, int U);
+hipError_t launch_log_softmax_gather_skewed(hipStream_t stream, const float* logits, const int* labels,
+                                            float* ws2, int N, int T, int U, int V, int blank);
+hipError_t launch_expand(hipStream_t stream, const float* g2_skewed, const int* labels,
+                         const int* xn, const int* yn, const float* scale, float* dense, int N,
+                         int T, int U, int V, int blank, int overwrite_mode);
+
+}  // namespace rnnt

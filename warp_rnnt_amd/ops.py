@@ -1,0 +1,89 @@
+"""Torch-tensor front ends of the native entry points (device memory + streams only)."""
+import torch
+
+from . import _lib
+from ._lib import (GRADS_DENSE, GRADS_GATHERED, GRADS_GATHERED_DIAGONAL, GRADS_NONE,  # noqa: F401
+                   IN_LOG_PROBS_DENSE, IN_LOG_PROBS_GATHERED, IN_LOGITS_DENSE, STATUS_NAMES)
+
+
+def _ptr(t):
+    return 0 if t is None else t.data_ptr()
+
+
+def _stream(device):
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def _check(status):
+    if status != 0:
+        # same text as the reference's TORCH_CHECK (binding.cpp:102-103)
+        raise RuntimeError("rnnt_loss status " + str(status) +
+                           " (" + STATUS_NAMES.get(status, "?") + ")")
+
+
+def loss(input, labels, xn, yn, input_kind, grads_kind, blank=0, fastemit_lambda=0.0):
+    """costs (N,), grads (layout per grads_kind; None for GRADS_NONE). Tensors must be validated
+    by the caller (contiguous, fp32/int32, same GPU)."""
+    L = _lib.load()
+    N, T, U, V = input.shape
+    dev = input.device
+    with torch.cuda.device(dev):
+        costs = torch.empty((N,), dtype=torch.float32, device=dev)
+        if grads_kind == GRADS_DENSE:
+            grads = torch.empty_like(input)
+        elif grads_kind == GRADS_NONE:
+            grads = None
+        else:
+            grads = torch.empty((N, T, U, 2), dtype=torch.float32, device=dev)
+        if N == 0:
+            return costs, grads
+        ws_bytes = L.rnnt_amd_workspace_size(N, T, U)
+        if ws_bytes == 0:
+            raise RuntimeError("rnnt_loss status 5 (RNNT_STATUS_INVALID_ARGUMENT): unsupported sizes "
+                               f"N={N} T={T} U={U}")
+        ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
+        st = L.rnnt_amd_loss(_stream(dev), ws.data_ptr(), input_kind, input.data_ptr(), _ptr(labels),
+                             xn.data_ptr(), yn.data_ptr(), costs.data_ptr(), _ptr(grads), grads_kind,
+                             N, T, U, V, max(blank, 0), float(fastemit_lambda))
+        _check(st)
+    return costs, grads
+
+
+def expand_grads(grads_diagonal, labels, xn, yn, grad_costs, V, blank, overwrite=False):
+    """Dense (N,T,U,V) d/d log_probs from diagonal-major gathered grads, scaled per utterance."""
+    L = _lib.load()
+    N, T, U, _ = grads_diagonal.shape
+    dev = grads_diagonal.device
+    with torch.cuda.device(dev):
+        out = torch.empty((N, T, U, V), dtype=torch.float32, device=dev)
+        if N == 0:
+            return out
+        st = L.rnnt_amd_expand_grads(_stream(dev), grads_diagonal.data_ptr(), _ptr(labels), xn.data_ptr(),
+                                     yn.data_ptr(), _ptr(grad_costs), out.data_ptr(), N, T, U, V, blank,
+                                     1 if overwrite else 0)
+        _check(st)
+    return out
+
+
+def log_softmax(x, out=None):
+    """Row-wise log-softmax over the last axis (fp32, contiguous, GPU). ``out`` may be ``x``."""
+    L = _lib.load()
+    assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous()
+    if out is None:
+        out = torch.empty_like(x)
+    V = x.shape[-1]
+    rows = x.numel() // max(V, 1)
+    with torch.cuda.device(x.device):
+        _check(L.rnnt_amd_log_softmax(_stream(x.device), x.data_ptr(), out.data_ptr(), rows, V))
+    return out
+
+
+def gather(log_probs, labels, blank=0):
+    """(N,T,U,V) -> (N,T,U,2) [blank, label] pairs (row-major), as the reference wrapper builds them."""
+    L = _lib.load()
+    N, T, U, V = log_probs.shape
+    out = torch.empty((N, T, U, 2), dtype=torch.float32, device=log_probs.device)
+    with torch.cuda.device(log_probs.device):
+        _check(L.rnnt_amd_gather(_stream(log_probs.device), log_probs.data_ptr(), _ptr(labels),
+                                 out.data_ptr(), N, T, U, V, blank))
+    return out
