@@ -32,19 +32,25 @@ namespace rnnt {
 constexpr int K = 8;          // diagonals per block (= inter-wave lag)
 constexpr int RING = 4 * K;   // mailbox ring entries per wave boundary
 constexpr int MAXW = 16;      // waves per workgroup
+constexpr int MAIL_TRASH = WAVE + K;   // per-wave dump area for the lanes that are not lane 63
 
 struct Cell { float b, l; };  // blank / label log-prob of one lattice cell
 
-// Log-probs of the cell on forward diagonal `row`/`dF` in lattice column u.
-//   SKEWED:    row = dF mod T is enough.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+constexpr int RSRC_WORD3 = 0x00020000;   // raw buffer, 32-bit data format (gfx90a/gfx94x/gfx950)
+constexpr int OOB = (int)0x80000000;     // voffset beyond any num_records: loads return 0, stores drop
+
+// Log-probs of the cell on forward diagonal row (= dF mod T) in lattice column u.
+//   SKEWED:    the row is enough: one coalesced 8-byte buffer load, row offset in an SGPR.
 //   ROWMAJOR2: needs t = dF - u (clamped for lanes outside the lattice).
 //   DENSE:     same, plus the label index of column u (lab < 0: no label, use blank).
 template <int LOADER>
-__device__ __forceinline__ Cell load_cell(const LatticeArgs& a, size_t nbase, int row, int t, int u,
-                                          int lab) {
+__device__ __forceinline__ Cell load_cell(const LatticeArgs& a, __amdgpu_buffer_rsrc_t rs, size_t nbase,
+                                          int row, int t, int u, int lab) {
     Cell c;
     if constexpr (LOADER == LOAD_SKEWED) {
-        const float2 v = reinterpret_cast<const float2*>(a.lp)[nbase + (size_t)row * a.U + u];
+        const f32x2 v = __builtin_bit_cast(
+            f32x2, __builtin_amdgcn_raw_buffer_load_b64(rs, u * 8, row * a.U * 8, 0));
         c.b = v.x; c.l = v.y;
     } else if constexpr (LOADER == LOAD_ROWMAJOR2) {
         const float2 v = reinterpret_cast<const float2*>(a.lp)[nbase + (size_t)t * a.U + u];
@@ -57,17 +63,58 @@ __device__ __forceinline__ Cell load_cell(const LatticeArgs& a, size_t nbase, in
     return c;
 }
 
+// K consecutive diagonals of one wave.  MASKED: some lane of the wave starts or finishes inside
+// the block, so state updates are predicated per lane; otherwise every lane is live throughout.
+template <bool BETA, bool MASKED>
+__device__ __forceinline__ void run_block(const Cell (&cur)[K], const float mvec, float& Y, float& X,
+                                          const int d0, const int ucol_chk, const int Tn,
+                                          __amdgpu_buffer_rsrc_t rs_out, const int voff_out, int& row_st,
+                                          const int T, const int U, float* mail_slot) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const float first = readlane(mvec, k);
+        const float left = wave_shr1(first, X);
+        float val, Yn, Xn;
+        if constexpr (BETA) {
+            val = lse(Y + cur[k].b, left + cur[k].l);
+            Yn = val; Xn = val;
+        } else {
+            val = lse(Y, left);
+            Yn = val + cur[k].b;
+            Xn = val + cur[k].l;
+        }
+        // live cell <=> 0 <= d - ucol < Tn (ucol_chk is huge for columns outside the lattice)
+        const bool live = (unsigned)(d0 + k - ucol_chk) < (unsigned)Tn;
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, val), rs_out,
+                                              (MASKED && !live) ? OOB : voff_out, row_st * U * 4, 0);
+        if constexpr (MASKED) {
+            Y = live ? Yn : Y;
+            X = live ? Xn : X;
+        } else {
+            Y = Yn; X = Xn;
+        }
+        mail_slot[k] = X;   // only lane 63's pointer aims at the mailbox, the others at a dump area
+        row_st = BETA ? (row_st == 0 ? T - 1 : row_st - 1) : (row_st + 1 == T ? 0 : row_st + 1);
+    }
+}
+
 template <int LOADER, bool BETA>
-__device__ __forceinline__ void sweep(const LatticeArgs& a, const int n, float (*mail)[RING]) {
+__device__ __forceinline__ void sweep(const LatticeArgs& a, const int n, float (*mail)[RING],
+                                      float (*trash)[MAIL_TRASH]) {
     const int T = a.T, U = a.U;
     const int Tn = a.xn[n], Un = a.yn[n] + 1;
     const int lane = threadIdx.x & (WAVE - 1);
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform
     const int nw = blockDim.x >> 6;
     const size_t nbase = (size_t)n * T * U;
-    float* __restrict__ out = (BETA ? a.betas : a.alphas) + nbase;
+    float* out = (BETA ? a.betas : a.alphas) + nbase;
     const int ndiag = Tn + Un - 1;
     const float NEG_INF = -__builtin_inff();
+    const __amdgpu_buffer_rsrc_t rs_out =
+        __builtin_amdgcn_make_buffer_rsrc(out, 0, T * U * 4, RSRC_WORD3);
+    const __amdgpu_buffer_rsrc_t rs_lp = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(a.lp) + (LOADER == LOAD_SKEWED ? nbase * 2 : 0), 0,
+        LOADER == LOAD_SKEWED ? T * U * 8 : 0, RSRC_WORD3);
 
     for (int c0 = 0; c0 < Un; c0 += blockDim.x) {
         // ---- per-lane column bookkeeping (sweep coordinates: beta runs mirrored) ----
@@ -75,7 +122,7 @@ __device__ __forceinline__ void sweep(const LatticeArgs& a, const int n, float (
         const bool colvalid = ucol < Un;
         const int u = BETA ? (Un - 1 - ucol) : ucol;     // lattice column
         const int uc = min(max(u, 0), U - 1);            // address-safe column
-        const int ucol_chk = colvalid ? ucol : 0x40000000;  // makes the store predicate false
+        const int ucol_chk = colvalid ? ucol : 0x40000000;  // makes the live predicate false
         int lab = -1;
         if constexpr (LOADER == LOAD_DENSE) {
             if (uc < U - 1) lab = a.labels[(size_t)n * (U - 1) + uc];
@@ -89,41 +136,23 @@ __device__ __forceinline__ void sweep(const LatticeArgs& a, const int n, float (
 
         float Y = (ucol == 0) ? 0.0f : NEG_INF;   // alpha: alpha+lpB of own previous cell; beta: beta
         float X = NEG_INF;                        // alpha: alpha+lpL handed to the right; beta: beta
-        Cell cur[K], nxt[K];
+        Cell bufA[K], bufB[K];   // ping-pong: one holds the current block, the other the prefetch
         int row_nxt = 0;   // row (dF mod T) of the first diagonal of the block to prefetch next
         int row_st = 0;    // row of the diagonal being computed (store row)
         bool primed = false;
+        const int voff_out = colvalid ? uc * 4 : OOB;
 
-        for (int b = 0; b < nblk; ++b) {
+        // One block of this wave: global block b, log-probs in `cur`, prefetching into `nxt`.
+        // (Two buffers + a 2x unrolled loop instead of copying nxt->cur: a register copy would
+        // force `s_waitcnt vmcnt(0)` at the end of every block, which on gfx950 also drains the
+        // alpha/beta stores just issued.)
+        auto do_block = [&](const int b, Cell (&cur)[K], Cell (&nxt)[K]) {
             const int lb = b - w;   // local block of this wave (one block behind wave w-1)
             if (w < nwa && lb >= lo && lb < hi) {
                 const int d0 = lb * K;
-                // -- log-probs: the first live block loads synchronously, later ones were prefetched --
-                if (!primed) {
-                    const int dF0 = BETA ? (ndiag - 1 - d0) : d0;
-                    row_st = ((dF0 % T) + T) % T;
-                    row_nxt = row_st;
-#pragma unroll
-                    for (int k = 0; k < K; ++k) {
-                        const int tt = d0 + k - ucol;
-                        const int t = min(max(BETA ? (Tn - 1 - tt) : tt, 0), T - 1);
-                        cur[k] = load_cell<LOADER>(a, nbase, row_nxt, t, uc, lab);
-                        row_nxt = BETA ? (row_nxt == 0 ? T - 1 : row_nxt - 1)
-                                       : (row_nxt + 1 == T ? 0 : row_nxt + 1);
-                    }
-                    primed = true;
-                }
-                // -- prefetch the next block's K diagonals (always in-bounds, may be unused) --
-#pragma unroll
-                for (int k = 0; k < K; ++k) {
-                    const int tt = d0 + K + k - ucol;
-                    const int t = min(max(BETA ? (Tn - 1 - tt) : tt, 0), T - 1);
-                    nxt[k] = load_cell<LOADER>(a, nbase, row_nxt, t, uc, lab);
-                    row_nxt = BETA ? (row_nxt == 0 ? T - 1 : row_nxt - 1)
-                                   : (row_nxt + 1 == T ? 0 : row_nxt + 1);
-                }
-
-                // -- boundary column of this block: K values for diagonals d0-1 .. d0+K-2 --
+                // -- boundary column of this block: K values for diagonals d0-1 .. d0+K-2.
+                //    Fetched BEFORE the prefetch loads are issued so that waiting for it does
+                //    not drain them (vmcnt retires in order).
                 float mvec = NEG_INF;
                 if (w > 0) {
                     if (lane < K) mvec = mail[w - 1][(d0 - 1 + lane) & (RING - 1)];
@@ -138,47 +167,49 @@ __device__ __forceinline__ void sweep(const LatticeArgs& a, const int n, float (
                         if constexpr (!BETA) {
                             int labb = -1;
                             if constexpr (LOADER == LOAD_DENSE) labb = a.labels[(size_t)n * (U - 1) + ub];
-                            v += load_cell<LOADER>(a, nbase, rb, dd - (c0 - 1), ub, labb).l;
+                            v += load_cell<LOADER>(a, rs_lp, nbase, rb, dd - (c0 - 1), ub, labb).l;
                         }
                         mvec = v;
                     }
                 }
-
-                float mout = 0.0f;
-                const bool masked = d0 < wave_c + WAVE;   // some lane of the wave has not started yet
+                // -- log-probs: the first live block loads synchronously, later ones were prefetched --
+                if (!primed) {
+                    const int dF0 = BETA ? (ndiag - 1 - d0) : d0;
+                    row_st = ((dF0 % T) + T) % T;
+                    row_nxt = row_st;
+#pragma unroll
+                    for (int k = 0; k < K; ++k) {
+                        const int tt = d0 + k - ucol;
+                        const int t = min(max(BETA ? (Tn - 1 - tt) : tt, 0), T - 1);
+                        cur[k] = load_cell<LOADER>(a, rs_lp, nbase, row_nxt, t, uc, lab);
+                        row_nxt = BETA ? (row_nxt == 0 ? T - 1 : row_nxt - 1)
+                                       : (row_nxt + 1 == T ? 0 : row_nxt + 1);
+                    }
+                    primed = true;
+                }
+                // -- prefetch the next block's K diagonals (always in-bounds, may be unused) --
 #pragma unroll
                 for (int k = 0; k < K; ++k) {
-                    const int d = d0 + k;
-                    const float first = readlane(mvec, k);
-                    const float left = wave_shr1(first, X);
-                    float val, Yn, Xn;
-                    if constexpr (BETA) {
-                        val = lse(Y + cur[k].b, left + cur[k].l);
-                        Yn = val; Xn = val;
-                    } else {
-                        val = lse(Y, left);
-                        Yn = val + cur[k].b;
-                        Xn = val + cur[k].l;
-                    }
-                    if ((unsigned)(d - ucol_chk) < (unsigned)Tn) out[(size_t)row_st * U + uc] = val;
-                    if constexpr (!BETA) {
-                        // alpha-side log-likelihood alpha[T-1,U-1] + lpB[T-1,U-1] (core_gather.cu:339)
-                        if (d == ndiag - 1 && ucol == Un - 1) a.ll[n] = Yn;
-                    }
-                    if (masked) {
-                        const bool started = d >= ucol;
-                        Y = started ? Yn : Y;
-                        X = started ? Xn : X;
-                    } else {
-                        Y = Yn; X = Xn;
-                    }
-                    mout = (lane == k) ? readlane(X, WAVE - 1) : mout;   // collect lane 63's hand-over
-                    row_st = BETA ? (row_st == 0 ? T - 1 : row_st - 1)
-                                  : (row_st + 1 == T ? 0 : row_st + 1);
+                    const int tt = d0 + K + k - ucol;
+                    const int t = min(max(BETA ? (Tn - 1 - tt) : tt, 0), T - 1);
+                    nxt[k] = load_cell<LOADER>(a, rs_lp, nbase, row_nxt, t, uc, lab);
+                    row_nxt = BETA ? (row_nxt == 0 ? T - 1 : row_nxt - 1)
+                                   : (row_nxt + 1 == T ? 0 : row_nxt + 1);
                 }
-                if (w + 1 < nwa && lane < K) mail[w][(d0 + lane) & (RING - 1)] = mout;
-#pragma unroll
-                for (int k = 0; k < K; ++k) cur[k] = nxt[k];
+
+                // lane 63 of a wave with a right neighbour publishes X; everyone else dumps it
+                float* mail_slot = (lane == WAVE - 1 && w + 1 < nwa) ? &mail[w][d0 & (RING - 1)]
+                                                                     : &trash[w][lane];
+                // every lane live for the whole block?  (started: d0 >= last lane's column;
+                // not finished: d0+K-1 - first column < Tn; all 64 columns inside the lattice)
+                const bool full = (d0 >= wave_c + WAVE - 1) && (d0 + K <= wave_c + Tn) &&
+                                  (wave_c + WAVE <= Un);
+                if (full)
+                    run_block<BETA, false>(cur, mvec, Y, X, d0, ucol_chk, Tn, rs_out, voff_out, row_st, T, U,
+                                           mail_slot);
+                else
+                    run_block<BETA, true>(cur, mvec, Y, X, d0, ucol_chk, Tn, rs_out, voff_out, row_st, T, U,
+                                          mail_slot);
             }
             if (nwa > 1) {
                 // LDS-only release/acquire around the barrier: global prefetches stay in flight.
@@ -186,6 +217,17 @@ __device__ __forceinline__ void sweep(const LatticeArgs& a, const int n, float (
                 __builtin_amdgcn_s_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
             }
+        };
+
+        for (int b = 0; b < nblk; b += 2) {
+            do_block(b, bufA, bufB);
+            if (b + 1 < nblk) do_block(b + 1, bufB, bufA);
+        }
+        if constexpr (!BETA) {
+            // Y of a finished lane is frozen at alpha + lpB of its last live cell: for the last
+            // column that is the alpha-side log-likelihood alpha[T-1,U-1] + lpB[T-1,U-1]
+            // (core_gather.cu:339)
+            if (ucol == Un - 1) a.ll[n] = Y;
         }
         if (c0 + (int)blockDim.x < Un) {
             // next stripe reads column c0+blockDim.x-1 of `out` written by this workgroup
@@ -198,11 +240,12 @@ __device__ __forceinline__ void sweep(const LatticeArgs& a, const int n, float (
 template <int LOADER>
 __global__ void __launch_bounds__(MAXW * WAVE) k_lattice(const LatticeArgs a) {
     __shared__ float mail[MAXW][RING];
+    __shared__ float trash[MAXW][MAIL_TRASH];
     const int n = blockIdx.x >> 1;
     if (blockIdx.x & 1)
-        sweep<LOADER, true>(a, n, mail);
+        sweep<LOADER, true>(a, n, mail, trash);
     else
-        sweep<LOADER, false>(a, n, mail);
+        sweep<LOADER, false>(a, n, mail, trash);
 }
 
 hipError_t launch_lattice(hipStream_t stream, const LatticeArgs& a, int N, int loader) {
