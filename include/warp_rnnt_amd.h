@@ -121,6 +121,11 @@ rnntStatus_t rnnt_amd_log_softmax(rnntStream_t stream, const float *x, float *ou
 rnntStatus_t rnnt_amd_gather(rnntStream_t stream, const float *log_probs, const int *labels,
                              float *gathered, int N, int T, int U, int V, int blank);
 
+/* Diagnostics (used by tools/lattice_probe.py): re-run only the alpha/beta sweep on the
+ * (blank,label) pairs a previous rnnt_amd_loss call left in `workspace`. */
+rnntStatus_t rnnt_amd_debug_lattice_only(rnntStream_t stream, void *workspace, const int *xn,
+                                         const int *yn, int N, int T, int U);
+
 /* Library version, for the host-side loader. */
 int rnnt_amd_version(void);
 

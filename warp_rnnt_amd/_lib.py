@@ -32,6 +32,7 @@ SYMBOLS = {
     "rnnt_amd_expand_grads": (_i, [_vp] * 7 + [_i] * 6),
     "rnnt_amd_log_softmax": (_i, [_vp, _vp, _vp, _i64, _i]),
     "rnnt_amd_gather": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i]),
+    "rnnt_amd_debug_lattice_only": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i]),
     "rnnt_amd_version": (_i, []),
 }
 

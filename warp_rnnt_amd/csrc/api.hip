@@ -140,6 +140,18 @@ rnntStatus_t rnnt_amd_loss(rnntStream_t stream, void* workspace, int input_kind,
     return RNNT_STATUS_SUCCESS;
 }
 
+// Diagnostics: run only the alpha/beta sweep on whatever the workspace holds (after a call to
+// rnnt_amd_loss the (blank,label) pairs are still there unless grads were produced in place).
+rnntStatus_t rnnt_amd_debug_lattice_only(rnntStream_t stream, void* workspace, const int* xn,
+                                         const int* yn, int N, int T, int U) {
+    if (!dims_ok(N, T, U) || !workspace) return RNNT_STATUS_INVALID_ARGUMENT;
+    Workspace w;
+    carve(workspace, N, T, U, &w);
+    LatticeArgs la{w.ws2, nullptr, xn, yn, w.alphas, w.betas, w.ll, T, U, 2, 0};
+    if (launch_lattice(stream, la, N, LOAD_SKEWED) != hipSuccess) return RNNT_STATUS_WARP_FAILED;
+    return RNNT_STATUS_SUCCESS;
+}
+
 rnntStatus_t rnnt_amd_expand_grads(rnntStream_t stream, const float* grads_diagonal, const int* labels,
                                    const int* xn, const int* yn, const float* grad_costs,
                                    float* dense_grads, int N, int T, int U, int V, int blank,

@@ -24,12 +24,27 @@
 //     block ahead; alphas/betas are written in the same diagonal-major layout
 //     with coalesced stores.
 //   Critical path: (T_n + U_n - 1) + K*(waves-1) dependent lse steps.
+#include <type_traits>
+
 #include "common.h"
 #include "kernels.h"
 
 namespace rnnt {
 
-constexpr int K = 8;          // diagonals per block (= inter-wave lag)
+#ifndef RNNT_K
+#define RNNT_K 8
+#endif
+constexpr int K = RNNT_K;     // diagonals per block (= inter-wave lag)
+// Register ring of NB blocks: log-probs are prefetched NB-1 blocks ahead (24 diagonals for the
+// diagonal-major loader: an L2-miss/MALL round trip is ~1 us, a block ~0.3 us).  The two
+// reference-layout loaders need 64-bit addresses per load and keep a 2-deep ring.
+#ifndef RNNT_STORE_AUX
+#define RNNT_STORE_AUX 0
+#endif
+#ifndef RNNT_NB
+#define RNNT_NB 4
+#endif
+template <int LOADER> constexpr int ring_depth() { return LOADER == LOAD_SKEWED ? RNNT_NB : 2; }
 constexpr int RING = 4 * K;   // mailbox ring entries per wave boundary
 constexpr int MAXW = 16;      // waves per workgroup
 constexpr int MAIL_TRASH = WAVE + K;   // per-wave dump area for the lanes that are not lane 63
@@ -70,32 +85,105 @@ __device__ __forceinline__ void run_block(const Cell (&cur)[K], const float mvec
                                           const int d0, const int ucol_chk, const int Tn,
                                           __amdgpu_buffer_rsrc_t rs_out, const int voff_out, int& row_st,
                                           const int T, const int U, float* mail_slot) {
+    // Hoisted out of the dependency chain: the K boundary values (SGPRs) and the K store row
+    // offsets.  A single wave issues in order and a dependent VALU op costs ~6-11 cycles on
+    // gfx950 while an independent one costs ~3, so everything that is not lse() is kept short
+    // and early.
+    float first[K];
+    int soff[K];
 #pragma unroll
-    for (int k = 0; k < K; ++k) {
-        const float first = readlane(mvec, k);
-        const float left = wave_shr1(first, X);
-        float val, Yn, Xn;
-        if constexpr (BETA) {
-            val = lse(Y + cur[k].b, left + cur[k].l);
-            Yn = val; Xn = val;
-        } else {
-            val = lse(Y, left);
-            Yn = val + cur[k].b;
-            Xn = val + cur[k].l;
+    for (int k = 0; k < K; ++k) first[k] = readlane(mvec, k);
+    const int rowbytes = U * 4;
+    const bool nowrap = BETA ? (row_st >= K - 1) : (row_st + K <= T);
+    if (nowrap) {
+        const int base = row_st * rowbytes;
+#pragma unroll
+        for (int k = 0; k < K; ++k) soff[k] = BETA ? base - k * rowbytes : base + k * rowbytes;
+        row_st = BETA ? row_st - K : row_st + K;
+        if (BETA) { if (row_st < 0) row_st += T; } else { if (row_st >= T) row_st -= T; }
+    } else {
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            soff[k] = row_st * rowbytes;
+            row_st = BETA ? (row_st == 0 ? T - 1 : row_st - 1) : (row_st + 1 == T ? 0 : row_st + 1);
         }
-        // live cell <=> 0 <= d - ucol < Tn (ucol_chk is huge for columns outside the lattice)
-        const bool live = (unsigned)(d0 + k - ucol_chk) < (unsigned)Tn;
-        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, val), rs_out,
-                                              (MASKED && !live) ? OOB : voff_out, row_st * U * 4, 0);
+    }
+    // Hand-ordered step: a single wave issues in order, so the store / mailbox write / helper ops
+    // are placed in the latency shadow of the dependent chain
+    //   dpp -> add -> sub -> mul -> exp2 -> add -> log2 -> fma -> add
+    // and pinned there with sched_barrier (the compiler otherwise puts the store of step k
+    // between val(k) and the DPP that starts step k+1).  Stores and mailbox writes trail one
+    // step behind the values they publish.
+#define RNNT_PIN() __builtin_amdgcn_sched_barrier(0)
+    float pval = 0.0f, pX = 0.0f;     // value / hand-over of the previous step, still to be stored
+    int pvoff = OOB;
+#pragma unroll
+    for (int k = 0; k <= K; ++k) {
+        float left = 0.0f, skip = 0.0f;
+        if (k < K) {
+            left = wave_shr1(first[k], X);                                   // chain
+            RNNT_PIN();
+            if constexpr (BETA) skip = Y + cur[k].b;
+            RNNT_PIN();
+        }
+        if (k > 0) {
+#ifndef RNNT_PROBE_NOSTORE
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, pval), rs_out, pvoff, soff[k - 1], RNNT_STORE_AUX);
+#endif
+            RNNT_PIN();
+        }
+        if (k == K) {
+#ifndef RNNT_PROBE_NOMAIL
+            mail_slot[k - 1] = pX;
+#endif
+            break;
+        }
+        float emit;
+        if constexpr (BETA) { emit = left + cur[k].l; } else { emit = left; skip = Y; }   // chain
+        RNNT_PIN();
+        if (k > 0) {
+#ifndef RNNT_PROBE_NOMAIL
+            mail_slot[k - 1] = pX;   // only lane 63's pointer aims at the mailbox, the others at a dump area
+#endif
+            RNNT_PIN();
+        }
+        // ---- lse(skip, emit), see common.h ----
+        const float t = skip - emit;                                                   // chain
+        RNNT_PIN();
+        float mx;
+        asm("v_max_f32 %0, %1, %2" : "=v"(mx) : "v"(skip), "v"(emit));                 // shadow
+        RNNT_PIN();
+        const float m = -__builtin_fabsf(t) * 1.44269504088896340736f;                 // chain
+        RNNT_PIN();
+        const bool live = (unsigned)(d0 + k - ucol_chk) < (unsigned)Tn;                // shadow
+        RNNT_PIN();
+        const float e = __builtin_amdgcn_exp2f(m);                                     // chain
+        RNNT_PIN();
+        const float u = 1.0f + e;                                                      // chain
+        RNNT_PIN();
+        const float l2 = __builtin_amdgcn_logf(u);                                     // chain
+        RNNT_PIN();
+        const float c = e - (u - 1.0f);                                                // shadow
+        RNNT_PIN();
+        const float l = __builtin_fmaf(l2, 0.693147180559945309417f, c);               // chain
+        RNNT_PIN();
+        const float val = mx + l;                                                      // chain
+        RNNT_PIN();
+        float Yn, Xn;
+        if constexpr (BETA) { Yn = val; Xn = val; }
+        else { Xn = val + cur[k].l; RNNT_PIN(); Yn = val + cur[k].b; }
+        pval = val;
+        pvoff = (MASKED && !live) ? OOB : voff_out;
         if constexpr (MASKED) {
             Y = live ? Yn : Y;
             X = live ? Xn : X;
         } else {
             Y = Yn; X = Xn;
         }
-        mail_slot[k] = X;   // only lane 63's pointer aims at the mailbox, the others at a dump area
-        row_st = BETA ? (row_st == 0 ? T - 1 : row_st - 1) : (row_st + 1 == T ? 0 : row_st + 1);
+        pX = X;
+        RNNT_PIN();
     }
+#undef RNNT_PIN
 }
 
 template <int LOADER, bool BETA>
@@ -110,13 +198,18 @@ __device__ __forceinline__ void sweep(const LatticeArgs& a, const int n, float (
     float* out = (BETA ? a.betas : a.alphas) + nbase;
     const int ndiag = Tn + Un - 1;
     const float NEG_INF = -__builtin_inff();
+    constexpr int NB = ring_depth<LOADER>();
     const __amdgpu_buffer_rsrc_t rs_out =
         __builtin_amdgcn_make_buffer_rsrc(out, 0, T * U * 4, RSRC_WORD3);
     const __amdgpu_buffer_rsrc_t rs_lp = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(a.lp) + (LOADER == LOAD_SKEWED ? nbase * 2 : 0), 0,
         LOADER == LOAD_SKEWED ? T * U * 8 : 0, RSRC_WORD3);
 
-    for (int c0 = 0; c0 < Un; c0 += blockDim.x) {
+    // One column stripe of up to blockDim.x columns.  FIRST (c0 == 0) is the common case and is
+    // compiled separately: later stripes fetch their boundary column with global loads, and
+    // merely having that path in the block prologue makes the compiler drain the prefetch queue.
+    auto stripe = [&](auto first_tag, const int c0) {
+        constexpr bool FIRST = decltype(first_tag)::value;
         // ---- per-lane column bookkeeping (sweep coordinates: beta runs mirrored) ----
         const int ucol = c0 + (int)threadIdx.x;          // column in sweep coordinates
         const bool colvalid = ucol < Un;
@@ -136,19 +229,46 @@ __device__ __forceinline__ void sweep(const LatticeArgs& a, const int n, float (
 
         float Y = (ucol == 0) ? 0.0f : NEG_INF;   // alpha: alpha+lpB of own previous cell; beta: beta
         float X = NEG_INF;                        // alpha: alpha+lpL handed to the right; beta: beta
-        Cell bufA[K], bufB[K];   // ping-pong: one holds the current block, the other the prefetch
+        Cell bufs[NB][K];  // register ring, always indexed with compile-time constants
         int row_nxt = 0;   // row (dF mod T) of the first diagonal of the block to prefetch next
         int row_st = 0;    // row of the diagonal being computed (store row)
-        bool primed = false;
         const int voff_out = colvalid ? uc * 4 : OOB;
 
-        // One block of this wave: global block b, log-probs in `cur`, prefetching into `nxt`.
-        // (Two buffers + a 2x unrolled loop instead of copying nxt->cur: a register copy would
-        // force `s_waitcnt vmcnt(0)` at the end of every block, which on gfx950 also drains the
+        // One block of this wave: global block b = PH (mod NB); its log-probs sit in bufs[PH] and
+        // the block NB-1 ahead is prefetched into bufs[PH-1], the buffer the previous block freed.
+        // (A ring + an NB-times unrolled loop instead of copying registers: a copy would force
+        // `s_waitcnt vmcnt(0)` at the end of every block, which on gfx950 also drains the
         // alpha/beta stores just issued.)
-        auto do_block = [&](const int b, Cell (&cur)[K], Cell (&nxt)[K]) {
-            const int lb = b - w;   // local block of this wave (one block behind wave w-1)
-            if (w < nwa && lb >= lo && lb < hi) {
+        auto load_block = [&](Cell (&dst)[K], const int dblk) {   // diagonals dblk*K ..., rows from row_nxt
+            int rows[K];
+            const bool nowrap = BETA ? (row_nxt >= K - 1) : (row_nxt + K <= T);
+            if (nowrap) {
+#pragma unroll
+                for (int k = 0; k < K; ++k) rows[k] = BETA ? row_nxt - k : row_nxt + k;
+                row_nxt = BETA ? row_nxt - K : row_nxt + K;
+                if (BETA) { if (row_nxt < 0) row_nxt += T; } else { if (row_nxt >= T) row_nxt -= T; }
+            } else {
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    rows[k] = row_nxt;
+                    row_nxt = BETA ? (row_nxt == 0 ? T - 1 : row_nxt - 1)
+                                   : (row_nxt + 1 == T ? 0 : row_nxt + 1);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                int t = 0;
+                if constexpr (LOADER != LOAD_SKEWED) {
+                    const int tt = dblk * K + k - ucol;
+                    t = min(max(BETA ? (Tn - 1 - tt) : tt, 0), T - 1);
+                }
+                dst[k] = load_cell<LOADER>(a, rs_lp, nbase, rows[k], t, uc, lab);
+            }
+        };
+        auto do_block = [&](const int lb, auto ph) {
+            constexpr int PH = decltype(ph)::value;
+            Cell (&cur)[K] = bufs[PH];
+            {
                 const int d0 = lb * K;
                 // -- boundary column of this block: K values for diagonals d0-1 .. d0+K-2.
                 //    Fetched BEFORE the prefetch loads are issued so that waiting for it does
@@ -156,7 +276,7 @@ __device__ __forceinline__ void sweep(const LatticeArgs& a, const int n, float (
                 float mvec = NEG_INF;
                 if (w > 0) {
                     if (lane < K) mvec = mail[w - 1][(d0 - 1 + lane) & (RING - 1)];
-                } else if (c0 > 0) {
+                } else if (!FIRST) {
                     // stripe boundary: the previous pass of this workgroup left column c0-1 in `out`
                     const int dd = d0 - 1 + lane;               // sweep diagonal of the neighbour cell
                     if (lane < K && dd >= c0 - 1 && dd - (c0 - 1) < Tn) {
@@ -172,30 +292,8 @@ __device__ __forceinline__ void sweep(const LatticeArgs& a, const int n, float (
                         mvec = v;
                     }
                 }
-                // -- log-probs: the first live block loads synchronously, later ones were prefetched --
-                if (!primed) {
-                    const int dF0 = BETA ? (ndiag - 1 - d0) : d0;
-                    row_st = ((dF0 % T) + T) % T;
-                    row_nxt = row_st;
-#pragma unroll
-                    for (int k = 0; k < K; ++k) {
-                        const int tt = d0 + k - ucol;
-                        const int t = min(max(BETA ? (Tn - 1 - tt) : tt, 0), T - 1);
-                        cur[k] = load_cell<LOADER>(a, rs_lp, nbase, row_nxt, t, uc, lab);
-                        row_nxt = BETA ? (row_nxt == 0 ? T - 1 : row_nxt - 1)
-                                       : (row_nxt + 1 == T ? 0 : row_nxt + 1);
-                    }
-                    primed = true;
-                }
-                // -- prefetch the next block's K diagonals (always in-bounds, may be unused) --
-#pragma unroll
-                for (int k = 0; k < K; ++k) {
-                    const int tt = d0 + K + k - ucol;
-                    const int t = min(max(BETA ? (Tn - 1 - tt) : tt, 0), T - 1);
-                    nxt[k] = load_cell<LOADER>(a, rs_lp, nbase, row_nxt, t, uc, lab);
-                    row_nxt = BETA ? (row_nxt == 0 ? T - 1 : row_nxt - 1)
-                                   : (row_nxt + 1 == T ? 0 : row_nxt + 1);
-                }
+                // -- prefetch block lb+NB-1 (always in-bounds addresses, may be unused) --
+                load_block(bufs[(PH + NB - 1) % NB], lb + NB - 1);
 
                 // lane 63 of a wave with a right neighbour publishes X; everyone else dumps it
                 float* mail_slot = (lane == WAVE - 1 && w + 1 < nwa) ? &mail[w][d0 & (RING - 1)]
@@ -211,17 +309,51 @@ __device__ __forceinline__ void sweep(const LatticeArgs& a, const int n, float (
                     run_block<BETA, true>(cur, mvec, Y, X, d0, ucol_chk, Tn, rs_out, voff_out, row_st, T, U,
                                           mail_slot);
             }
+#ifndef RNNT_PROBE_NOBARRIER
             if (nwa > 1) {
                 // LDS-only release/acquire around the barrier: global prefetches stay in flight.
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
                 __builtin_amdgcn_s_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
             }
+#endif
         };
 
-        for (int b = 0; b < nblk; b += 2) {
-            do_block(b, bufA, bufB);
-            if (b + 1 < nblk) do_block(b + 1, bufB, bufA);
+        auto barrier_only = [&]() {
+            if (nwa > 1) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+            }
+        };
+        // Every wave executes exactly nblk barriers: idle ones before its first live block
+        // (global block lo+w), one per live block, idle ones after its last.  The live range is a
+        // straight-line NB-times unrolled loop so that the compiler's vmcnt bookkeeping is exact
+        // and the prefetched loads really stay in flight across blocks.
+        const bool wave_live = (w < nwa) && (lo < hi);
+        const int first_b = wave_live ? lo + w : nblk;
+        for (int b = 0; b < first_b; ++b) barrier_only();
+        if (wave_live) {
+            {   // fill the ring: blocks lo .. lo+NB-2 (the loop prefetches lo+NB-1 onwards)
+                const int dF0 = BETA ? (ndiag - 1 - lo * K) : lo * K;
+                row_st = ((dF0 % T) + T) % T;
+                row_nxt = row_st;
+                load_block(bufs[0], lo);
+                if constexpr (NB > 2) load_block(bufs[1], lo + 1);
+                if constexpr (NB > 3) load_block(bufs[2], lo + 2);
+                static_assert(NB >= 2 && NB <= 4, "ring depth");
+            }
+            int lb = lo;
+            for (; lb + NB <= hi; lb += NB) {
+                do_block(lb, std::integral_constant<int, 0>{});
+                do_block(lb + 1, std::integral_constant<int, 1 % NB>{});
+                if constexpr (NB > 2) do_block(lb + 2, std::integral_constant<int, 2 % NB>{});
+                if constexpr (NB > 3) do_block(lb + 3, std::integral_constant<int, 3 % NB>{});
+            }
+            if (lb < hi) { do_block(lb, std::integral_constant<int, 0>{}); ++lb; }
+            if (lb < hi) { do_block(lb, std::integral_constant<int, 1 % NB>{}); ++lb; }
+            if constexpr (NB > 3) { if (lb < hi) { do_block(lb, std::integral_constant<int, 2 % NB>{}); ++lb; } }
+            for (int b = hi + w; b < nblk; ++b) barrier_only();
         }
         if constexpr (!BETA) {
             // Y of a finished lane is frozen at alpha + lpB of its last live cell: for the last
@@ -234,7 +366,9 @@ __device__ __forceinline__ void sweep(const LatticeArgs& a, const int n, float (
             __threadfence_block();
             __syncthreads();
         }
-    }
+    };
+    stripe(std::true_type{}, 0);
+    for (int c0 = blockDim.x; c0 < Un; c0 += blockDim.x) stripe(std::false_type{}, c0);
 }
 
 template <int LOADER>
