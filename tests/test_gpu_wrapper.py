@@ -1,0 +1,110 @@
+"""GPU tests of the drop-in Python API (warp_rnnt.rnnt_loss) against fixtures produced by the
+REFERENCE's own wrapper (tests/golden/make_wrapper_fixtures.py) and against the oracle."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from helpers import GOLDEN, make_case, np_log_softmax32
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def T(a):
+    a = np.asarray(a)
+    return torch.tensor(a if a.ndim == 0 else np.ascontiguousarray(a), device=DEV)
+
+
+def test_wrapper_fixtures_from_reference_wrapper():
+    """loss values and log_probs.grad for every (blank, gather, reduction, average_frames, lambda)
+    combination, with a random upstream gradient."""
+    import warp_rnnt
+    fx = np.load(os.path.join(GOLDEN, "wrapper_fixtures.npz"))
+    lp0 = np_log_softmax32(fx["logits"])
+    xn, yn = T(fx["xn"]), T(fx["yn"])
+    for row in fx["cases"]:
+        key, blank, gather, reduction, avg, lam, _ = row.split(";")
+        lp = T(lp0).requires_grad_(True)
+        loss = warp_rnnt.rnnt_loss(lp, T(fx[key + "_labels"]), xn, yn, average_frames=bool(int(avg)),
+                                   reduction=reduction, blank=int(blank), gather=bool(int(gather)),
+                                   fastemit_lambda=float(lam))
+        np.testing.assert_allclose(loss.detach().cpu().numpy(), fx[key + "_loss"], rtol=1e-5, err_msg=row)
+        loss.backward(T(fx[key + "_up"]))
+        np.testing.assert_allclose(lp.grad.cpu().numpy(), fx[key + "_grad"], atol=2e-6, err_msg=row)
+
+
+def test_gather_true_equals_dense_path():
+    """tensorflow_binding/warp_rnnt_tf/test.py:227-252: wrapper-level gather=True must give the
+    dense (N,T,U,V) gradients of the gather=False path."""
+    import warp_rnnt
+    logits, labels, xn, yn = make_case(21, 4, 33, 70, 9, ragged=True)
+    lp0 = np_log_softmax32(logits)
+    grads = []
+    for gather in (False, True):
+        lp = T(lp0).requires_grad_(True)
+        loss = warp_rnnt.rnnt_loss(lp, T(labels), T(xn), T(yn), gather=gather, reduction="sum",
+                                   fastemit_lambda=0.01)
+        loss.backward()
+        grads.append((loss.item(), lp.grad.cpu().numpy()))
+    assert grads[0][0] == grads[1][0]
+    np.testing.assert_array_equal(grads[0][1], grads[1][1])
+    ref = oracle.rnnt_loss_f32(lp0, labels, xn, yn, fastemit_lambda=0.01, scan_mode=1)
+    np.testing.assert_allclose(grads[0][1], ref["grads"], atol=1e-4)
+
+
+def test_forward_computes_grads_without_requires_grad_and_second_backward():
+    """Appendix B: grads are produced in forward; backward is a broadcast multiply and can be
+    repeated (the reference multiplies in place, which would double-scale)."""
+    import warp_rnnt
+    logits, labels, xn, yn = make_case(2, 2, 12, 5, 6)
+    lp = T(np_log_softmax32(logits))
+    c = warp_rnnt.rnnt_loss(lp, T(labels), T(xn), T(yn))          # no grad needed: still fine
+    assert c.shape == (2,) and not c.requires_grad
+    lp.requires_grad_(True)
+    c = warp_rnnt.rnnt_loss(lp, T(labels), T(xn), T(yn))
+    g1, = torch.autograd.grad(c.sum() * 3.0, lp, retain_graph=True)
+    g2, = torch.autograd.grad(c.sum() * 3.0, lp)
+    assert torch.equal(g1, g2)
+
+
+def test_log_softmax_then_loss_matches_fused_from_logits():
+    """The fused logits entry (log-softmax + gather in one kernel) gives the same costs/gathered
+    grads as log_softmax followed by the gather path."""
+    from warp_rnnt_amd import ops
+    logits, labels, xn, yn = make_case(8, 3, 40, 21, 50, ragged=True)
+    x = T(logits)
+    c1, g1 = ops.loss(ops.log_softmax(x), T(labels), T(xn), T(yn), ops.IN_LOG_PROBS_DENSE,
+                      ops.GRADS_GATHERED, 0, 0.0)
+    c2, g2 = ops.loss(x, T(labels), T(xn), T(yn), ops.IN_LOGITS_DENSE, ops.GRADS_GATHERED, 0, 0.0)
+    np.testing.assert_allclose(c1.cpu().numpy(), c2.cpu().numpy(), rtol=1e-6)
+    np.testing.assert_allclose(g1.cpu().numpy(), g2.cpu().numpy(), atol=1e-5)
+
+
+def test_sharded_loss_single_process():
+    from warp_rnnt_amd.distributed import sharded_rnnt_loss
+    logits, labels, xn, yn = make_case(4, 5, 20, 7, 8, ragged=True)
+    lp0 = np_log_softmax32(logits)
+    lp = T(lp0).requires_grad_(True)
+    loss, glob = sharded_rnnt_loss(lp, T(labels), T(xn), T(yn), reduction="mean", gather=True)
+    ref = oracle.rnnt_loss_f32(lp0, labels, xn, yn, scan_mode=1)
+    np.testing.assert_allclose(glob.item(), ref["costs"].mean(), rtol=1e-5)
+    loss.backward()
+    np.testing.assert_allclose(lp.grad.cpu().numpy(), ref["grads"] / 5.0, atol=1e-5)
+
+
+def test_non_default_stream_and_device_guard():
+    """Launches go to the caller's current stream (binding.cpp:77) and are ordered with it."""
+    import warp_rnnt
+    logits, labels, xn, yn = make_case(9, 2, 30, 9, 6)
+    lp0 = np_log_softmax32(logits)
+    ref = oracle.rnnt_loss_f32(lp0, labels, xn, yn, scan_mode=1)
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        lp = T(lp0) * 1.0                       # produced on stream s
+        c = warp_rnnt.rnnt_loss(lp, T(labels), T(xn), T(yn), gather=True)
+        tot = c.sum()
+    s.synchronize()
+    np.testing.assert_allclose(tot.item(), ref["costs"].sum(), rtol=1e-5)

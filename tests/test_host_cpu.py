@@ -1,0 +1,178 @@
+"""CPU-side checks (no GPU): C-ABI library loads and exports every declared symbol, the drop-in
+package validates arguments like the reference binding, fixtures are self-consistent, and the
+multi-rank reduction is correct on a world_size-2 gloo group."""
+import os
+import re
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from helpers import GOLDEN, np_log_softmax32
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_header_symbols_exported():
+    """Every function include/warp_rnnt_amd.h declares is exported by the built library and
+    bound by the ctypes loader (no compute calls: there is no GPU here)."""
+    import warp_rnnt_amd
+    from warp_rnnt_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "warp_rnnt_amd.h")).read()
+    declared = set(re.findall(r"\b(run_warp_rnnt(?:_gather)?|rnnt_amd_[a-z_]+)\s*\(", hdr))
+    assert {"run_warp_rnnt", "run_warp_rnnt_gather", "rnnt_amd_loss", "rnnt_amd_expand_grads",
+            "rnnt_amd_log_softmax", "rnnt_amd_gather", "rnnt_amd_workspace_size"} <= declared
+    assert declared == set(_lib.SYMBOLS), (declared ^ set(_lib.SYMBOLS))
+    L = warp_rnnt_amd.load()
+    for name in declared:
+        assert getattr(L, name) is not None
+    assert L.rnnt_amd_version() >= 100
+    # pure host-side entry point: sizes
+    assert L.rnnt_amd_workspace_size(16, 1500, 300) >= 16 * 1500 * 300 * 16
+    assert L.rnnt_amd_workspace_size(1, 0, 3) == 0          # invalid dims are rejected
+    syms = subprocess.check_output(["nm", "-D", "--defined-only", warp_rnnt_amd.lib_path()]).decode()
+    for name in declared:
+        assert re.search(r"\bT " + name + r"\b", syms), name
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    from warp_rnnt_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "_LIB_NAME", "libdoes_not_exist.so")
+    with pytest.raises(RuntimeError, match="has not been built"):
+        _lib.load()
+
+
+def test_product_never_imports_oracle():
+    """The product packages must not reference the oracle (or any CPU fallback)."""
+    for pkg in ("warp_rnnt", "warp_rnnt_amd"):
+        for dirpath, _, files in os.walk(os.path.join(ROOT, pkg)):
+            for f in files:
+                if f.endswith((".py", ".hip", ".h", ".cpp")):
+                    src = open(os.path.join(dirpath, f)).read()
+                    assert not re.search(r"^\s*(import|from)\s+oracle", src, re.M), os.path.join(dirpath, f)
+                    assert "librnnt_oracle" not in src
+
+
+def test_argument_validation_on_cpu():
+    """Order and texts of binding.cpp:32-51 that can be observed without a GPU (test.py:15-32)."""
+    import warp_rnnt._C as core
+    xs = torch.tensor([], dtype=torch.float32)
+    e = torch.tensor([], dtype=torch.int)
+    nc = torch.tensor(np.zeros((4, 3, 2, 1)), dtype=torch.float32).transpose(0, 1)
+    with pytest.raises(RuntimeError, match="xs must be contiguous"):
+        core.rnnt_loss(nc, e, e, e)
+    with pytest.raises(RuntimeError, match="xs must be located in the CUDA"):
+        core.rnnt_loss(xs, e, e, e)
+    with pytest.raises(RuntimeError, match="ys must be a Int tensor"):
+        core.rnnt_loss(xs, torch.tensor([], dtype=torch.long), e, e)
+    with pytest.raises(RuntimeError, match="xs must be a Float tensor"):
+        core.rnnt_loss(xs.half(), e, e, e)
+    with pytest.raises(RuntimeError, match="xn must be a Int tensor"):
+        core.rnnt_loss(xs, e, e.long(), e)
+
+
+def test_wrapper_asserts_and_reduction_errors():
+    import warp_rnnt
+    lp = torch.zeros((1, 2, 2, 3))
+    ys = torch.zeros((1, 1), dtype=torch.int)
+    n = torch.ones((1,), dtype=torch.int)
+    with pytest.raises(AssertionError):
+        warp_rnnt.rnnt_loss(lp, ys, n, n, reduction="avg")
+    with pytest.raises(AssertionError):
+        warp_rnnt.rnnt_loss(lp, ys, n, n, blank=0.0)
+    with pytest.raises(AssertionError):
+        warp_rnnt.rnnt_loss(lp, ys, n, n, gather=1)
+    with pytest.raises(RuntimeError, match="located in the CUDA"):
+        warp_rnnt.rnnt_loss(lp, ys, n, n)          # no CPU fallback
+
+
+def test_wrapper_fixtures_self_consistent():
+    """The fixtures generated from the reference's own wrapper: for gather=True the native op
+    receives the (N,T,U,2) [blank,label] gather with blank=-1 (__init__.py:118-128)."""
+    fx = np.load(os.path.join(GOLDEN, "wrapper_fixtures.npz"))
+    lp = np_log_softmax32(fx["logits"])
+    seen_gather = 0
+    for row in fx["cases"]:
+        key, blank, gather, reduction, avg, lam, native_blank = row.split(";")
+        blank, gather, native_blank = int(blank), int(gather), int(native_blank)
+        nin = fx[key + "_native_in"]
+        if gather:
+            seen_gather += 1
+            assert native_blank == -1 and nin.shape[-1] == 2
+            np.testing.assert_allclose(nin, oracle.gather_f32(lp, fx[key + "_labels"], blank), atol=1e-6)
+        else:
+            assert native_blank == blank
+            np.testing.assert_allclose(nin, lp, atol=1e-6)
+    assert seen_gather > 0
+
+
+def test_shard_bounds():
+    from warp_rnnt_amd.distributed import shard_bounds
+    for n in (0, 1, 7, 16, 128):
+        for world in (1, 2, 3, 8):
+            spans = [shard_bounds(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [hi - lo for lo, hi in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+WORKER = r'''
+import os, sys
+sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests"))
+import numpy as np, torch, torch.distributed as dist
+import oracle
+from helpers import make_case, np_log_softmax32
+from warp_rnnt_amd.distributed import reduce_costs, shard_bounds
+dist.init_process_group("gloo", rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]))
+rank, world = dist.get_rank(), dist.get_world_size()
+logits, labels, xn, yn = make_case(3, 5, 9, 4, 6, ragged=True)       # global batch of 5 on 2 ranks: 3 + 2
+lp = np_log_softmax32(logits)
+full = oracle.rnnt_loss_f32(lp, labels, xn, yn)
+lo, hi = shard_bounds(5, rank, world)
+mine = oracle.rnnt_loss_f32(lp[lo:hi], labels[lo:hi], xn[lo:hi], yn[lo:hi])
+np.testing.assert_array_equal(mine["costs"], full["costs"][lo:hi])       # utterances are independent
+costs = torch.tensor(mine["costs"], requires_grad=True)
+for red in ("sum", "mean"):
+    loss, glob = reduce_costs(costs, red)
+    want = full["costs"].sum() if red == "sum" else full["costs"].mean()
+    np.testing.assert_allclose(glob.item(), want, rtol=1e-6)
+    g, = torch.autograd.grad(loss, costs)
+    np.testing.assert_allclose(g.numpy(), np.full(hi - lo, 1.0 if red == "sum" else 1.0 / 5), rtol=1e-6)
+    # sum over ranks of the local losses is the global loss
+    t = loss.detach().clone(); dist.all_reduce(t)
+    np.testing.assert_allclose(t.item(), want, rtol=1e-6)
+_, allc = reduce_costs(costs, "none")
+np.testing.assert_array_equal(allc.numpy(), full["costs"])
+dist.barrier(); dist.destroy_process_group()
+print("rank", rank, "ok")
+'''
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_two_rank_reduction_gloo(tmp_path):
+    """world_size 2 on CPU (gloo): sharding + the scalar exchange of the multi-GPU path."""
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER.format(root=ROOT))
+    port = _free_port()
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT))
+    outs = [p.communicate(timeout=240)[0].decode() for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, o
+        assert f"rank {r} ok" in o
