@@ -37,7 +37,8 @@ size_t carve(void* base, int N, int T, int U, Workspace* w) {
 bool dims_ok(int N, int T, int U) {
     if (N < 0 || T < 1 || U < 1) return false;
     if (N > 65535) return false;                               // gridDim.y of the gradient kernel
-    if ((int64_t)T * U >= (int64_t)1 << 31) return false;      // per-utterance cell index is 32-bit
+    if ((int64_t)T * U >= (int64_t)1 << 29) return false;      // per-utterance plane < 4 GiB of float2 (buffer descriptors)
+    if ((int64_t)N * T * U >= (int64_t)1 << 32) return false;  // flat cell index is 32-bit
     return true;
 }
 

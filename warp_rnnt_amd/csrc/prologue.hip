@@ -40,70 +40,76 @@ struct CellMap {
 };
 __device__ __forceinline__ CellMap map_cell(size_t cell, const int* __restrict__ labels, int T, int U,
                                             int blank) {
-    const size_t frame = cell / (unsigned)U;          // n*T + t
-    const int u = (int)(cell - frame * (unsigned)U);
-    const size_t n = frame / (unsigned)T;
+    // N*T*U < 2^32 is checked by the C ABI, so 32-bit divisions are enough
+    const unsigned c32 = (unsigned)cell;
+    const unsigned frame = c32 / (unsigned)U;         // n*T + t
+    const int u = (int)(c32 - frame * (unsigned)U);
+    const unsigned n = frame / (unsigned)T;
     const int t = (int)(frame - n * (unsigned)T);
     int r = t + u;
     r = r >= T ? r % T : r;
     CellMap m;
-    m.sk = (n * T + r) * (size_t)U + u;
-    m.label = (u < U - 1) ? labels[n * (size_t)(U - 1) + u] : blank;
+    m.sk = ((size_t)n * T + r) * (size_t)U + u;
+    m.label = (u < U - 1) ? labels[(size_t)n * (U - 1) + u] : blank;
     return m;
 }
 
 // ---------------------------------------------------------------------------
 // Small vocabularies (V <= 1024): a workgroup stages R whole rows in LDS with
-// 16-byte coalesced loads, L lanes cooperate on a row, results leave with
-// 16-byte coalesced stores (or as one float2 per row for the fused gather).
-// LDS rows are padded to a stride S = L*odd so that the L-lane groups of a
-// 32-lane LDS access hit distinct banks.
+// 16-byte coalesced loads (ds_write_b128, rows kept at their natural stride V so
+// the tile is a byte copy of the global chunk), L lanes cooperate on a row, and
+// results leave with ds_read_b128 + 16-byte coalesced stores (or as one float2
+// per row for the fused gather).  The first version of this kernel was
+// VALU-bound, not HBM-bound (rocprofv3: 871 VALU instructions per wave, i.e.
+// ~70 per element: libm expf, per-element index division for padded LDS rows,
+// per-lane loop control); this one spends ~12.
+//   exp(x - max) is evaluated as exp2(x*log2e - max*log2e) on the hardware
+//   v_exp_f32 unit, log(sum) as v_log_f32 * ln2 (sum in [1,V]); both are within
+//   ~2 ulp, the result is within 4e-6 of torch.log_softmax (tests).
 // ---------------------------------------------------------------------------
 constexpr int SM_THREADS = 256;
-constexpr int SM_FLOATS = 6144;   // LDS tile budget in floats (24 KiB -> 6 workgroups per CU)
+#ifndef RNNT_SM_FLOATS
+#define RNNT_SM_FLOATS 3200
+#endif
+constexpr int SM_FLOATS = RNNT_SM_FLOATS;   // LDS tile budget in floats (12.5 KiB; smaller tiles = more resident workgroups, measured best)
+constexpr float LOG2E = 1.44269504088896340736f;
+constexpr float LN2 = 0.693147180559945309417f;
 
 template <int L, bool GATHER>
 __global__ void __launch_bounds__(SM_THREADS)
 k_lsm_small(const float* x, float* out, const int* __restrict__ labels,
-            int64_t rows, int V, int S, int R, int T, int U, int blank) {
+            int64_t rows, int V, int R, int q, int T, int U, int blank) {
     extern __shared__ __attribute__((aligned(16))) float tile[];
     const int tid = threadIdx.x;
     const int64_t row0 = (int64_t)blockIdx.x * R;
     const int nrows = (int)min((int64_t)R, rows - row0);
     const int nel = nrows * V;                      // floats in this chunk
-    const float* src = x + row0 * V;   // 16-byte aligned: R % 4 == 0 (out may alias x)
+    const float* src = x + row0 * V;                // 16-byte aligned: R % 4 == 0 (out may alias x)
 
-    // ---- stage: coalesced float4 loads, scattered into padded LDS rows ----
+    // ---- stage: the tile is a plain copy of the chunk ----
     const int nvec = nel >> 2;
-    for (int i = tid; i < nvec; i += SM_THREADS) {
-        const float4 v = reinterpret_cast<const float4*>(src)[i];
-        const int e = i << 2;
-        int r = e / V, c = e - r * V;
-        const float vv[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            tile[r * S + c] = vv[j];
-            if (++c == V) { c = 0; ++r; }
-        }
-    }
-    for (int e = (nvec << 2) + tid; e < nel; e += SM_THREADS) {   // tail (only in the last chunk)
-        const int r = e / V, c = e - r * V;
-        tile[r * S + c] = src[e];
-    }
+    for (int i = tid; i < nvec; i += SM_THREADS)
+        reinterpret_cast<float4*>(tile)[i] = reinterpret_cast<const float4*>(src)[i];
+    for (int e = (nvec << 2) + tid; e < nel; e += SM_THREADS) tile[e] = src[e];   // last chunk only
     __syncthreads();
 
-    // ---- per-row max / sum(exp) / normalise: L lanes per row ----
+    // ---- per-row max / sum(exp) / normalise: L lanes per row, lane h owns columns h, h+L, ... ----
     constexpr int RPP = SM_THREADS / L;             // rows per pass
     const int h = tid % L, rr = tid / L;
+    const int ctail = h + (q - 1) * L;              // this lane's last column, may be >= V
+    const bool tail_ok = ctail < V;
     for (int r = rr; r < nrows; r += RPP) {
-        float* row = tile + r * S;
+        float* row = tile + r * V;
         float mx = -__builtin_inff();
-        for (int c = h; c < V; c += L) mx = fmaxf(mx, row[c]);
+        for (int i = 0, c = h; i < q - 1; ++i, c += L) mx = fmaxf(mx, row[c]);
+        if (tail_ok) mx = fmaxf(mx, row[ctail]);
         mx = group_max<L>(mx);
+        const float mb = -mx * LOG2E;
         float s = 0.0f;
-        for (int c = h; c < V; c += L) s += expf(row[c] - mx);
+        for (int i = 0, c = h; i < q - 1; ++i, c += L) s += __builtin_amdgcn_exp2f(__builtin_fmaf(row[c], LOG2E, mb));
+        if (tail_ok) s += __builtin_amdgcn_exp2f(__builtin_fmaf(row[ctail], LOG2E, mb));
         s = group_sum<L>(s);
-        const float ls = logf(s);
+        const float ls = __builtin_amdgcn_logf(s) * LN2;
         if constexpr (GATHER) {
             if (h == 0) {
                 const CellMap m = map_cell((size_t)(row0 + r), labels, T, U, blank);
@@ -111,27 +117,16 @@ k_lsm_small(const float* x, float* out, const int* __restrict__ labels,
                     make_float2((row[blank] - mx) - ls, (row[m.label] - mx) - ls);
             }
         } else {
-            for (int c = h; c < V; c += L) row[c] = (row[c] - mx) - ls;
+            for (int i = 0, c = h; i < q - 1; ++i, c += L) row[c] = (row[c] - mx) - ls;
+            if (tail_ok) row[ctail] = (row[ctail] - mx) - ls;
         }
     }
     if constexpr (!GATHER) {
         __syncthreads();
         float* dst = out + row0 * V;
-        for (int i = tid; i < nvec; i += SM_THREADS) {
-            const int e = i << 2;
-            int r = e / V, c = e - r * V;
-            float vv[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                vv[j] = tile[r * S + c];
-                if (++c == V) { c = 0; ++r; }
-            }
-            reinterpret_cast<float4*>(dst)[i] = make_float4(vv[0], vv[1], vv[2], vv[3]);
-        }
-        for (int e = (nvec << 2) + tid; e < nel; e += SM_THREADS) {
-            const int r = e / V, c = e - r * V;
-            dst[e] = tile[r * S + c];
-        }
+        for (int i = tid; i < nvec; i += SM_THREADS)
+            reinterpret_cast<float4*>(dst)[i] = reinterpret_cast<const float4*>(tile)[i];
+        for (int e = (nvec << 2) + tid; e < nel; e += SM_THREADS) dst[e] = tile[e];
     }
 }
 
@@ -174,11 +169,14 @@ k_lsm_large(const float* x, float* out, const int* __restrict__ labels,
         }
     }
     mx = block_reduce(mx, true, red);
+    const float mb = -mx * LOG2E;
     float s = 0.0f;
 #pragma unroll
     for (int i = 0; i < LG_MAXVEC; ++i) {
         const int j = threadIdx.x + i * LG_THREADS;
-        if (j < nvec) s += (expf(v[i].x - mx) + expf(v[i].y - mx)) + (expf(v[i].z - mx) + expf(v[i].w - mx));
+        if (j < nvec)
+            s += (__builtin_amdgcn_exp2f(__builtin_fmaf(v[i].x, LOG2E, mb)) + __builtin_amdgcn_exp2f(__builtin_fmaf(v[i].y, LOG2E, mb))) +
+                 (__builtin_amdgcn_exp2f(__builtin_fmaf(v[i].z, LOG2E, mb)) + __builtin_amdgcn_exp2f(__builtin_fmaf(v[i].w, LOG2E, mb)));
     }
     s = block_reduce(s, false, red);
     const float ls = logf(s);
@@ -240,20 +238,16 @@ static hipError_t dispatch_lsm(hipStream_t stream, const float* x, float* out, c
                          (GATHER || reinterpret_cast<uintptr_t>(out) % 16 == 0);
     if (aligned && V <= 1024) {
         int L = 1;
-        while (L < 64 && L * 16 < V) L <<= 1;          // ~<=16 elements per lane
-        int q = (V + L - 1) / L;
-        if (L < 32 && (q & 1) == 0) ++q;               // stride = L*odd: conflict-free row groups
-        const int S = (L < 32) ? L * q : V;
-        int R = SM_FLOATS / S;
-        R = (R / 4) * 4;
-        if (R < 4) R = 4;
-        const int rpp = SM_THREADS / L;
-        if (R > rpp) R = (R / rpp) * rpp;              // whole passes (rpp is a multiple of 4)
-        const size_t lds = (size_t)R * S * sizeof(float);
+        while (L < 64 && L * 16 < V) L <<= 1;          // <= 16 columns per lane
+        const int q = (V + L - 1) / L;
+        const int rpp = SM_THREADS / L;                // rows per pass, a multiple of 4
+        int R = (SM_FLOATS / V) / rpp * rpp;           // whole passes
+        if (R < rpp) R = rpp;
+        const size_t lds = (size_t)R * V * sizeof(float);
         const unsigned grid = (unsigned)((rows + R - 1) / R);
 #define LSM_SMALL(LL)                                                                           \
     case LL:                                                                                    \
-        k_lsm_small<LL, GATHER><<<grid, SM_THREADS, lds, stream>>>(x, out, labels, rows, V, S, R, T, \
+        k_lsm_small<LL, GATHER><<<grid, SM_THREADS, lds, stream>>>(x, out, labels, rows, V, R, q, T, \
                                                                     U, blank);                  \
         break;
         switch (L) {
@@ -281,56 +275,100 @@ hipError_t launch_log_softmax_gather_skewed(hipStream_t stream, const float* log
 }
 
 // ---------------------------------------------------------------------------
-// gather: dense log-probs -> diagonal-major (blank,label) pairs. One thread per
-// cell, lanes along u: the float2 stores of one t-row land on U different
-// diagonals (8-byte scattered stores, merged in L2), the reads are two 4-byte
-// accesses per 4V-byte row.
+// To-diagonal kernels: dense log-probs (gather) or row-major pairs (re-layout) ->
+// diagonal-major (blank,label) pairs.  A workgroup owns a 32x32 (t,u) tile of one
+// utterance: it reads the tile with lanes along u (the contiguous axis of the
+// source), parks it in LDS, and writes it back diagonal by diagonal, so that
+// every store instruction covers contiguous runs of up to 32 pairs (256 B) of a
+// diagonal-major row.  (One thread per cell writing its pair directly costs 4.6x
+// write amplification: rocprofv3 WRITE_SIZE 268 MB for a 57.6 MB output.)
 // ---------------------------------------------------------------------------
-template <bool SKEWED>
+constexpr int TD = 32;   // tile edge
+
+template <bool DENSE>
 __global__ void __launch_bounds__(256)
-k_gather(const float* __restrict__ lp, const int* __restrict__ labels, float2* __restrict__ out2,
-         size_t cells, int T, int U, int V, int blank) {
+k_to_diagonal(const float* __restrict__ src, const int* __restrict__ labels, float2* __restrict__ ws2,
+              int T, int U, int V, int blank, int tiles_t, int tiles_u) {
+    __shared__ float2 tile[TD][TD];
+    unsigned b = blockIdx.x;
+    const int tu = b % tiles_u; b /= tiles_u;
+    const int tt = b % tiles_t;
+    const int n = b / tiles_t;
+    const int t0 = tt * TD, u0 = tu * TD;
+    const int ul = threadIdx.x & (TD - 1), tl0 = threadIdx.x >> 5;   // 8 rows of 32 lanes
+    const int u = u0 + ul;
+    const size_t nbase = (size_t)n * T * U;
+    int lab = blank;
+    if (DENSE && u < U - 1) lab = labels[(size_t)n * (U - 1) + u];
+#pragma unroll
+    for (int k = 0; k < TD / 8; ++k) {
+        const int tl = tl0 + 8 * k, t = t0 + tl;
+        if (t < T && u < U) {
+            const size_t cell = nbase + (size_t)t * U + u;
+            if constexpr (DENSE) {
+                const float* p = src + cell * (size_t)V;
+                tile[tl][ul] = make_float2(p[blank], p[lab]);
+            } else {
+                tile[tl][ul] = reinterpret_cast<const float2*>(src)[cell];
+            }
+        }
+    }
+    __syncthreads();
+    // diagonal d of the tile holds cells (tl = d - ul, ul): consecutive ul = consecutive pairs of
+    // row (t0+u0+d) mod T of the diagonal-major plane
+#pragma unroll
+    for (int k = 0; k < (2 * TD) / 8; ++k) {
+        const int d = tl0 + 8 * k;
+        const int tl = d - ul;
+        if (d < 2 * TD - 1 && tl >= 0 && tl < TD) {
+            const int t = t0 + tl;
+            if (t < T && u < U) {
+                int r = t + u;
+                r = r >= T ? r % T : r;
+                ws2[nbase + (size_t)r * U + u] = tile[tl][ul];
+            }
+        }
+    }
+}
+
+// Row-major (N,T,U,2) gather (what the reference's wrapper builds): one thread per cell.
+__global__ void __launch_bounds__(256)
+k_gather_rowmajor(const float* __restrict__ lp, const int* __restrict__ labels, float2* __restrict__ out2,
+                  size_t cells, int T, int U, int V, int blank) {
     const size_t cell = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (cell >= cells) return;
     const CellMap m = map_cell(cell, labels, T, U, blank);
     const float* p = lp + cell * (size_t)V;
-    out2[SKEWED ? m.sk : cell] = make_float2(p[blank], p[m.label]);
+    out2[cell] = make_float2(p[blank], p[m.label]);
+}
+
+static hipError_t launch_to_diagonal(hipStream_t stream, const float* src, const int* labels, float* ws2,
+                                     int N, int T, int U, int V, int blank, bool dense) {
+    if ((size_t)N * T * U == 0) return hipSuccess;
+    const int tiles_t = (T + TD - 1) / TD, tiles_u = (U + TD - 1) / TD;
+    const size_t nblk = (size_t)N * tiles_t * tiles_u;
+    if (nblk >= ((size_t)1 << 31)) return hipErrorInvalidValue;
+    if (dense)
+        k_to_diagonal<true><<<(unsigned)nblk, 256, 0, stream>>>(src, labels, reinterpret_cast<float2*>(ws2), T, U,
+                                                                V, blank, tiles_t, tiles_u);
+    else
+        k_to_diagonal<false><<<(unsigned)nblk, 256, 0, stream>>>(src, labels, reinterpret_cast<float2*>(ws2), T, U,
+                                                                 2, 0, tiles_t, tiles_u);
+    return hipGetLastError();
 }
 
 hipError_t launch_gather(hipStream_t stream, const float* log_probs, const int* labels, float* out2,
                          int N, int T, int U, int V, int blank, bool skewed) {
     const size_t cells = (size_t)N * T * U;
     if (cells == 0) return hipSuccess;
-    const unsigned grid = (unsigned)((cells + 255) / 256);
-    if (skewed)
-        k_gather<true><<<grid, 256, 0, stream>>>(log_probs, labels, reinterpret_cast<float2*>(out2),
-                                                 cells, T, U, V, blank);
-    else
-        k_gather<false><<<grid, 256, 0, stream>>>(log_probs, labels, reinterpret_cast<float2*>(out2),
-                                                  cells, T, U, V, blank);
+    if (skewed) return launch_to_diagonal(stream, log_probs, labels, out2, N, T, U, V, blank, true);
+    k_gather_rowmajor<<<(unsigned)((cells + 255) / 256), 256, 0, stream>>>(
+        log_probs, labels, reinterpret_cast<float2*>(out2), cells, T, U, V, blank);
     return hipGetLastError();
-}
-
-// (N,T,U,2) row-major -> diagonal-major. Same cell walk, 8-byte coalesced reads.
-__global__ void __launch_bounds__(256)
-k_reskew(const float2* __restrict__ in, float2* __restrict__ ws2, size_t cells, int T, int U) {
-    const size_t cell = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (cell >= cells) return;
-    const size_t frame = cell / (unsigned)U;
-    const int u = (int)(cell - frame * (unsigned)U);
-    const size_t n = frame / (unsigned)T;
-    const int t = (int)(frame - n * (unsigned)T);
-    int r = t + u;
-    r = r >= T ? r % T : r;
-    ws2[(n * T + r) * (size_t)U + u] = in[cell];
 }
 
 hipError_t launch_reskew(hipStream_t stream, const float* lp2_rowmajor, float* ws2, int N, int T, int U) {
-    const size_t cells = (size_t)N * T * U;
-    if (cells == 0) return hipSuccess;
-    k_reskew<<<(unsigned)((cells + 255) / 256), 256, 0, stream>>>(
-        reinterpret_cast<const float2*>(lp2_rowmajor), reinterpret_cast<float2*>(ws2), cells, T, U);
-    return hipGetLastError();
+    return launch_to_diagonal(stream, lp2_rowmajor, nullptr, ws2, N, T, U, 2, 0, false);
 }
 
 }  // namespace rnnt
