@@ -162,6 +162,12 @@ def main():
     k_ms = sum(x.elapsed_time(y) for x, y in zip(ev_a, ev_b)) / a.steps
     alg_bytes = 8.0 * V * cells      # unfused log-softmax = 8V B/cell (4V read + 4V write)
     achieved = alg_bytes / (k_ms * 1e-3) / 1e9
+    traffic = None                   # measured HBM bytes per launch (PMC passes, see profiles/hbm_traffic.json)
+    try:
+        with open(os.path.join(ROOT, "profiles", "hbm_traffic.json")) as f:
+            traffic = json.load(f).get(a.config, {}).get("traffic_bytes")
+    except OSError:
+        pass
 
     extras = {}
     if rank == 0 and not inplace:
@@ -205,7 +211,7 @@ def main():
             "loss_checksum": round(loss_val, 3),
             "roofline": {"bound": "hbm", "kernel": "k_lsm_small/k_lsm_large (log-softmax over V)",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "algorithmic_bytes": alg_bytes, "kernel_ms": round(k_ms, 4)},
         }
         out.update(extras)

@@ -46,7 +46,10 @@ constexpr int K = RNNT_K;     // diagonals per block (= inter-wave lag)
 #endif
 template <int LOADER> constexpr int ring_depth() { return LOADER == LOAD_SKEWED ? RNNT_NB : 2; }
 constexpr int RING = 4 * K;   // mailbox ring entries per wave boundary
-constexpr int MAXW = 16;      // waves per workgroup
+#ifndef RNNT_MAXW
+#define RNNT_MAXW 16
+#endif
+constexpr int MAXW = RNNT_MAXW;   // waves per workgroup
 constexpr int MAIL_TRASH = WAVE + K;   // per-wave dump area for the lanes that are not lane 63
 
 struct Cell { float b, l; };  // blank / label log-prob of one lattice cell
@@ -80,7 +83,7 @@ __device__ __forceinline__ Cell load_cell(const LatticeArgs& a, __amdgpu_buffer_
 
 // K consecutive diagonals of one wave.  MASKED: some lane of the wave starts or finishes inside
 // the block, so state updates are predicated per lane; otherwise every lane is live throughout.
-template <bool BETA, bool MASKED>
+template <bool BETA, bool MASKED, bool MAIL>
 __device__ __forceinline__ void run_block(const Cell (&cur)[K], const float mvec, float& Y, float& X,
                                           const int d0, const int ucol_chk, const int Tn,
                                           __amdgpu_buffer_rsrc_t rs_out, const int voff_out, int& row_st,
@@ -134,7 +137,7 @@ __device__ __forceinline__ void run_block(const Cell (&cur)[K], const float mvec
         }
         if (k == K) {
 #ifndef RNNT_PROBE_NOMAIL
-            mail_slot[k - 1] = pX;
+            if constexpr (MAIL) mail_slot[k - 1] = pX;
 #endif
             break;
         }
@@ -143,7 +146,8 @@ __device__ __forceinline__ void run_block(const Cell (&cur)[K], const float mvec
         RNNT_PIN();
         if (k > 0) {
 #ifndef RNNT_PROBE_NOMAIL
-            mail_slot[k - 1] = pX;   // only lane 63's pointer aims at the mailbox, the others at a dump area
+            // only lane 63's pointer aims at the mailbox, the others at a dump area
+            if constexpr (MAIL) mail_slot[k - 1] = pX;
 #endif
             RNNT_PIN();
         }
@@ -163,11 +167,17 @@ __device__ __forceinline__ void run_block(const Cell (&cur)[K], const float mvec
         RNNT_PIN();
         const float l2 = __builtin_amdgcn_logf(u);                                     // chain
         RNNT_PIN();
+#ifndef RNNT_LSE_UNCORRECTED
         const float c = e - (u - 1.0f);                                                // shadow
         RNNT_PIN();
         const float l = __builtin_fmaf(l2, 0.693147180559945309417f, c);               // chain
         RNNT_PIN();
         const float val = mx + l;                                                      // chain
+#else
+        // Probe only: max + ln2*log2(1+e) in one fma, rounding of 1+e left uncorrected.  4 % faster,
+        // but pushes gradients past the 1e-4 parity bar at T=150,U=40 -- not used.
+        const float val = __builtin_fmaf(l2, 0.693147180559945309417f, mx);            // chain
+#endif
         RNNT_PIN();
         float Yn, Xn;
         if constexpr (BETA) { Yn = val; Xn = val; }
@@ -302,12 +312,22 @@ __device__ __forceinline__ void sweep(const LatticeArgs& a, const int n, float (
                 // not finished: d0+K-1 - first column < Tn; all 64 columns inside the lattice)
                 const bool full = (d0 >= wave_c + WAVE - 1) && (d0 + K <= wave_c + Tn) &&
                                   (wave_c + WAVE <= Un);
-                if (full)
-                    run_block<BETA, false>(cur, mvec, Y, X, d0, ucol_chk, Tn, rs_out, voff_out, row_st, T, U,
-                                           mail_slot);
-                else
-                    run_block<BETA, true>(cur, mvec, Y, X, d0, ucol_chk, Tn, rs_out, voff_out, row_st, T, U,
-                                          mail_slot);
+                const bool has_right = w + 1 < nwa;   // someone consumes this wave's boundary column
+                if (full) {
+                    if (has_right)
+                        run_block<BETA, false, true>(cur, mvec, Y, X, d0, ucol_chk, Tn, rs_out, voff_out, row_st,
+                                                     T, U, mail_slot);
+                    else
+                        run_block<BETA, false, false>(cur, mvec, Y, X, d0, ucol_chk, Tn, rs_out, voff_out, row_st,
+                                                      T, U, mail_slot);
+                } else {
+                    if (has_right)
+                        run_block<BETA, true, true>(cur, mvec, Y, X, d0, ucol_chk, Tn, rs_out, voff_out, row_st,
+                                                    T, U, mail_slot);
+                    else
+                        run_block<BETA, true, false>(cur, mvec, Y, X, d0, ucol_chk, Tn, rs_out, voff_out, row_st,
+                                                     T, U, mail_slot);
+                }
             }
 #ifndef RNNT_PROBE_NOBARRIER
             if (nwa > 1) {
