@@ -113,6 +113,29 @@ rnntStatus_t rnnt_amd_expand_grads(rnntStream_t stream, const float *grads_diago
                                    float *dense_grads, int N, int T, int U, int V, int blank,
                                    int overwrite);
 
+/*
+ * Compact (ragged packed) layout -- replaces run_gather_for_compact + run_warp_rnnt_compact
+ * (core.h:41-54; core_compact.cu:360-436) with this ABI's conventions (status codes, caller's
+ * stream, no exit(), no host synchronisation).
+ *   xs (STU,V) log-probs, utterance n owning rows [cell_offsets[n], cell_offsets[n+1]) as a
+ *   (xn[n], yn[n]+1) row-major block; ys (sum yn,) packed labels; cell_offsets (N+1,) int64 and
+ *   label_offsets (N+1,) int32 exclusive prefix sums; Tmax/Umax = max xn / max yn+1 (launch bounds).
+ *   grads2 (STU,2) [blank,label] gradients, fully written (NULL = costs only);
+ *   loc (STU,) int64 vocabulary index of the label channel per row (NULL = not wanted).
+ */
+size_t rnnt_amd_workspace_size_compact(int N, int64_t STU);
+rnntStatus_t rnnt_amd_loss_compact(rnntStream_t stream, void *workspace, const float *xs, const int *ys,
+                                   const int *xn, const int *yn, const int64_t *cell_offsets,
+                                   const int *label_offsets, float *costs, float *grads2, int64_t *loc,
+                                   int N, int64_t STU, int Tmax, int Umax, int V, int blank,
+                                   float fastemit_lambda);
+
+/* Replaces run_scatter_grad_for_compact (core.h:56-60): (STU,V) d/d log_probs, fully written.
+ * cum_lens (N,) int32 inclusive prefix sums of xn*(yn+1) (warp_rnnt/__init__.py:38). */
+rnntStatus_t rnnt_amd_compact_scatter_grads(rnntStream_t stream, const float *grad_costs,
+                                            const float *grads2, const int64_t *loc, const int *cum_lens,
+                                            float *dense_grads, int64_t STU, int N, int V, int blank);
+
 /* Row-wise log-softmax over the last axis; out may alias x. */
 rnntStatus_t rnnt_amd_log_softmax(rnntStream_t stream, const float *x, float *out, int64_t rows, int V);
 

@@ -37,11 +37,57 @@ def stub_rnnt_loss(xs, ys, xn, yn, blank=0, fastemit_lambda=0.0):
     return torch.from_numpy(out["costs"].copy()), torch.from_numpy(out["grads"].copy())
 
 
+def _unpack(xs, ys, xn, yn):
+    """compact (STU,V)/(SU,) -> padded (N,Tm,Um,V)/(N,Um-1) (zeros in the padding)."""
+    N = len(xn)
+    Tm, Um, V = int(xn.max()), int(yn.max()) + 1, xs.shape[1]
+    lp = np.zeros((N, Tm, Um, V), dtype=np.float32)
+    lab = np.zeros((N, max(Um - 1, 1)), dtype=np.int32)
+    o = lo = 0
+    for n in range(N):
+        t, u = int(xn[n]), int(yn[n]) + 1
+        lp[n, :t, :u] = xs[o:o + t * u].reshape(t, u, V)
+        lab[n, :u - 1] = ys[lo:lo + u - 1]
+        o += t * u
+        lo += u - 1
+    return lp, lab[:, :max(Um - 1, 0)] if Um > 1 else lab[:, :0]
+
+
+def stub_rnnt_loss_compact(xs, ys, xn, yn, blank=0, fastemit_lambda=0.0, required_grad=True):
+    """binding.cpp:109-207 semantics on top of the padded oracle: (costs, grads (STU,2), loc (STU,))."""
+    xs_, ys_, xn_, yn_ = xs.detach().numpy(), ys.numpy(), xn.numpy(), yn.numpy()
+    lp, lab = _unpack(xs_, ys_, xn_, yn_)
+    lp2 = oracle.gather_f32(lp, lab, blank) if lab.shape[1] else np.stack([lp[..., blank]] * 2, -1)
+    out = oracle.rnnt_loss_f32(lp2, lab, xn_, yn_, blank=-1, fastemit_lambda=fastemit_lambda, scan_mode=1)
+    g, loc = [], []
+    for n in range(len(xn_)):
+        t, u = int(xn_[n]), int(yn_[n]) + 1
+        g.append(out["grads"][n, :t, :u].reshape(-1, 2))
+        l = np.full((t, u), blank, dtype=np.int64)
+        l[:, :u - 1] = lab[n, :u - 1][None, :]
+        loc.append(l.reshape(-1))
+    return (torch.from_numpy(out["costs"].copy()), torch.from_numpy(np.concatenate(g).copy()),
+            torch.from_numpy(np.concatenate(loc)))
+
+
+def stub_rnnt_loss_compact_backward(grad_cost, grad_xs, cum_lens, loc, V, blank):
+    """binding.cpp:209-247 / core_compact.cu:456-484."""
+    gc, g, cl, lc = grad_cost.numpy(), grad_xs.numpy(), cum_lens.numpy(), loc.numpy()
+    out = np.zeros((g.shape[0], V), dtype=np.float32)
+    n_of = np.searchsorted(cl, np.arange(g.shape[0]), side="right")
+    out[np.arange(g.shape[0]), blank] = g[:, 0] * gc[n_of]
+    m = lc != blank
+    out[np.arange(g.shape[0])[m], lc[m]] = (g[:, 1] * gc[n_of])[m]
+    return torch.from_numpy(out)
+
+
 def load_reference_wrapper():
     pkg = types.ModuleType("warp_rnnt")
     pkg.__path__ = []
     core = types.ModuleType("warp_rnnt._C")
     core.rnnt_loss = stub_rnnt_loss
+    core.rnnt_loss_compact = stub_rnnt_loss_compact
+    core.rnnt_loss_compact_backward = stub_rnnt_loss_compact_backward
     sys.modules["warp_rnnt"] = pkg
     sys.modules["warp_rnnt._C"] = core
     pkg._C = core
@@ -92,6 +138,29 @@ def main():
                         cases.append((key, blank, int(gather), reduction, int(average_frames), lam,
                                       int(calls[0]["blank"])))
                         cid += 1
+    # ---- compact layout (warp_rnnt/__init__.py:26-54,109-116) ----
+    ccases = []
+    lp_full = torch.log_softmax(torch.from_numpy(logits), dim=-1).numpy()
+    for blank in (0, 2):
+        choices = np.array([v for v in range(V) if v != blank], dtype=np.int32)
+        labels = choices[rng.randint(0, len(choices), size=(N, U - 1))].astype(np.int32)
+        xs_c = np.concatenate([lp_full[n, :xn[n], :yn[n] + 1].reshape(-1, V) for n in range(N)])
+        ys_c = np.concatenate([labels[n, :yn[n]] for n in range(N)]).astype(np.int32)
+        for reduction, average_frames, lam in (("none", False, 0.0), ("mean", True, 0.05), ("sum", False, 0.0)):
+            lp = torch.from_numpy(xs_c.copy()).requires_grad_(True)
+            loss = ref.rnnt_loss(lp, torch.from_numpy(ys_c), torch.from_numpy(xn), torch.from_numpy(yn),
+                                 average_frames=average_frames, reduction=reduction, blank=blank,
+                                 fastemit_lambda=lam, compact=True)
+            up = torch.tensor(np.asarray(rng.rand(*loss.shape) + 0.5, dtype=np.float32))
+            loss.backward(up)
+            key = f"k{len(ccases):03d}"
+            store[key + "_xs"] = xs_c
+            store[key + "_ys"] = ys_c
+            store[key + "_loss"] = loss.detach().numpy()
+            store[key + "_up"] = up.numpy()
+            store[key + "_grad"] = lp.grad.numpy()
+            ccases.append((key, blank, reduction, int(average_frames), lam))
+    store["compact_cases"] = np.array([";".join(map(str, c)) for c in ccases])
     store["cases"] = np.array([";".join(map(str, c)) for c in cases])
     out = os.path.join(HERE, "wrapper_fixtures.npz")
     np.savez_compressed(out, **store)

@@ -1,0 +1,104 @@
+"""GPU tests of the compact (ragged packed) layout: rnnt_loss(compact=True), _C.rnnt_loss_compact,
+_C.rnnt_loss_compact_backward (reference: core_compact.cu, binding.cpp:108-247, __init__.py:26-54)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from helpers import GOLDEN, make_case, np_log_softmax32, reference_doc
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def T(a):
+    a = np.asarray(a)
+    return torch.tensor(a if a.ndim == 0 else np.ascontiguousarray(a), device=DEV)
+
+
+def pack(lp, labels, xn, yn):
+    V = lp.shape[-1]
+    xs = np.concatenate([lp[n, :xn[n], :yn[n] + 1].reshape(-1, V) for n in range(lp.shape[0])])
+    ys = np.concatenate([labels[n, :yn[n]] for n in range(lp.shape[0])]).astype(np.int32)
+    return np.ascontiguousarray(xs), ys
+
+
+def test_reference_golden_compact():
+    """test.py:259-336: costs and the (15,5) scattered gradient rows."""
+    import warp_rnnt._C as core
+    case = [c for c in reference_doc()["cases"] if c["name"] == "forward_batch_compact"][0]
+    lp = np_log_softmax32(np.array(case["logits"], dtype=np.float32))
+    labels = np.array(case["labels"], dtype=np.int32)
+    xn = np.array(case["xn"], dtype=np.int32)
+    yn = np.array(case["yn"], dtype=np.int32)
+    xs, ys = pack(lp, labels, xn, yn)
+    costs, grads, loc = core.rnnt_loss_compact(T(xs), T(ys), T(xn), T(yn))
+    np.testing.assert_allclose(costs.cpu().numpy(), np.array(case["costs"]), atol=1.5e-6, rtol=0)
+    cumlen = torch.cumsum(T(xn) * (T(yn) + 1), dim=0, dtype=torch.int32)
+    dense = core.rnnt_loss_compact_backward(torch.ones_like(costs).contiguous(), grads, cumlen, loc,
+                                            lp.shape[-1], 0)
+    np.testing.assert_allclose(dense.cpu().numpy(), np.array(case["grads_rows"]), atol=1.5e-6, rtol=0)
+
+
+@pytest.mark.parametrize("N,Tm,Um,V,lam,blank", [
+    (5, 40, 12, 9, 0.0, 0),
+    (3, 70, 90, 5, 0.02, 2),      # two waves, ragged
+    (4, 9, 1, 4, 0.0, 0),         # no labels at all
+    (2, 33, 140, 6, 0.0, 1),      # V % 4 != 0 -> scalar scatter path
+])
+def test_compact_vs_oracle(N, Tm, Um, V, lam, blank):
+    import warp_rnnt._C as core
+    logits, labels, xn, yn = make_case(77 + Tm, N, Tm, Um, V, ragged=True, blank=blank)
+    lp = np_log_softmax32(logits)
+    ref = oracle.rnnt_loss_f32(lp, labels, xn, yn, blank=blank, fastemit_lambda=lam, scan_mode=1)
+    xs, ys = pack(lp, labels, xn, yn)
+    costs, grads, loc = core.rnnt_loss_compact(T(xs), T(ys), T(xn), T(yn), blank=blank, fastemit_lambda=lam)
+    np.testing.assert_allclose(costs.cpu().numpy(), ref["costs"], rtol=1e-5)
+    # loc: label index per row, blank on each utterance's last column
+    want_loc = []
+    for n in range(N):
+        l = np.full((xn[n], yn[n] + 1), blank, dtype=np.int64)
+        l[:, :yn[n]] = labels[n, :yn[n]][None, :]
+        want_loc.append(l.reshape(-1))
+    np.testing.assert_array_equal(loc.cpu().numpy(), np.concatenate(want_loc))
+    gc = np.random.RandomState(1).rand(N).astype(np.float32) + 0.5
+    cumlen = torch.cumsum(T(xn) * (T(yn) + 1), dim=0, dtype=torch.int32)
+    dense = core.rnnt_loss_compact_backward(T(gc), grads, cumlen, loc, V, blank).cpu().numpy()
+    want = np.concatenate([(ref["grads"][n, :xn[n], :yn[n] + 1] * gc[n]).reshape(-1, V) for n in range(N)])
+    np.testing.assert_allclose(dense, want, atol=1e-4)
+    # costs-only mode
+    c2, g2, _ = core.rnnt_loss_compact(T(xs), T(ys), T(xn), T(yn), blank=blank, fastemit_lambda=lam,
+                                       required_grad=False)
+    np.testing.assert_array_equal(c2.cpu().numpy(), costs.cpu().numpy())
+    assert g2.numel() == 0
+
+
+def test_compact_wrapper_fixtures_from_reference_wrapper():
+    import warp_rnnt
+    fx = np.load(os.path.join(GOLDEN, "wrapper_fixtures.npz"))
+    xn, yn = T(fx["xn"]), T(fx["yn"])
+    for row in fx["compact_cases"]:
+        key, blank, reduction, avg, lam = row.split(";")
+        lp = T(fx[key + "_xs"]).requires_grad_(True)
+        loss = warp_rnnt.rnnt_loss(lp, T(fx[key + "_ys"]), xn, yn, average_frames=bool(int(avg)),
+                                   reduction=reduction, blank=int(blank), fastemit_lambda=float(lam),
+                                   compact=True)
+        np.testing.assert_allclose(loss.detach().cpu().numpy(), fx[key + "_loss"], rtol=1e-5, err_msg=row)
+        loss.backward(T(fx[key + "_up"]))
+        np.testing.assert_allclose(lp.grad.cpu().numpy(), fx[key + "_grad"], atol=2e-6, err_msg=row)
+
+
+def test_compact_shape_errors():
+    import warp_rnnt._C as core
+    xs = torch.zeros((10, 4), device=DEV)
+    ys = torch.zeros((3,), dtype=torch.int, device=DEV)
+    xn = torch.tensor([2, 2], dtype=torch.int, device=DEV)
+    yn = torch.tensor([1, 1], dtype=torch.int, device=DEV)
+    with pytest.raises(RuntimeError, match="xs must have 2 dimensions"):
+        core.rnnt_loss_compact(xs.view(5, 2, 4), ys, xn, yn)
+    with pytest.raises(RuntimeError, match=r"ys shape must be equal to \(sum\(yn\), \)"):
+        core.rnnt_loss_compact(xs, ys, xn, yn)
+    with pytest.raises(RuntimeError, match="xs shape mismatch"):
+        core.rnnt_loss_compact(xs, ys[:2].contiguous(), xn, yn)

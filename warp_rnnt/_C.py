@@ -73,3 +73,45 @@ def rnnt_loss_gather(xs, ys, xn, yn, blank=0, fastemit_lambda=0.0):
 def rnnt_loss_gather_backward(grad_costs, grads_diagonal, ys, xn, yn, V, blank=0):
     """d loss / d log_probs (N,T,U,V) = scatter-add of the gathered grads times grad_costs[n]."""
     return _ops.expand_grads(grads_diagonal, ys, xn, yn, grad_costs, V, blank, overwrite=False)
+
+
+def rnnt_loss_compact(xs, ys, xn, yn, blank=0, fastemit_lambda=0.0, required_grad=True):
+    """binding.cpp:109-207: (costs (N,), grads (STU,2), loc (STU,) int64) for the compact layout
+    (xs (STU,V) with STU = sum(xn*(yn+1)), ys (sum(yn),)).  Same check order and messages."""
+    for x, name in ((xs, "xs"), (ys, "ys"), (xn, "xn"), (yn, "yn")):
+        _check_contiguous(x, name)
+    _check_float(xs, "xs")
+    for x, name in ((ys, "ys"), (xn, "xn"), (yn, "yn")):
+        _check_int(x, name)
+    for x, name in ((xs, "xs"), (ys, "ys"), (xn, "xn"), (yn, "yn")):
+        _check_cuda(x, name)
+    if xs.dim() != 2:
+        raise RuntimeError("xs must have 2 dimensions")
+    if xn.size(0) != yn.size(0):
+        raise RuntimeError("xn and yn shape must be equal (N,)")
+    costs, grads, loc = _ops.loss_compact(xs, ys, xn, yn, blank, fastemit_lambda, required_grad)
+    if grads is None:
+        grads = costs.new_empty((0, 2))    # the reference aliases an unused buffer here
+    return costs, grads, loc
+
+
+def rnnt_loss_compact_backward(grad_cost, grad_xs, cum_lens, loc, V, blank):
+    """binding.cpp:209-247: scatter the (STU,2) gradients, scaled per utterance, into (STU,V)."""
+    _check_contiguous(grad_cost, "grad_cost")
+    _check_contiguous(grad_xs, "grad_xs")
+    _check_contiguous(loc, "loc")
+    _check_float(grad_cost, "grad_cost")
+    _check_float(grad_xs, "grad_xs")
+    if loc.dtype != torch.int64:
+        raise RuntimeError("loc must be a Long tensor")
+    for x, name in ((grad_cost, "grad_cost"), (grad_xs, "grad_xs"), (cum_lens, "cum_lens"), (loc, "loc")):
+        _check_cuda(x, name)
+    if grad_cost.dim() != 1:
+        raise RuntimeError("grad_cost must have 1 dimensions")
+    if grad_xs.dim() != 2:
+        raise RuntimeError("grad must have 2 dimensions")
+    if grad_xs.size(0) != loc.size(0):
+        raise RuntimeError("grad and loc must be equal in dim=0")
+    if cum_lens.dtype != torch.int32 or not cum_lens.is_contiguous():
+        raise RuntimeError("cum_lens must be a contiguous Int tensor")
+    return _ops.compact_scatter_grads(grad_cost, grad_xs, cum_lens, loc, V, blank)

@@ -59,6 +59,37 @@ class RNNTLossGather(torch.autograd.Function):
         return dense, None, None, None, None, None
 
 
+class RNNTLossCompact(torch.autograd.Function):
+    """Compact (ragged packed) layout, mirror of __init__.py:26-54."""
+
+    @staticmethod
+    def forward(ctx, log_probs, labels, frames_lengths, labels_lengths, blank=0, fastemit_lambda=0.0,
+                enable_grad: bool = True):
+        costs, grads, loc = core.rnnt_loss_compact(
+            xs=log_probs, ys=labels,
+            xn=frames_lengths, yn=labels_lengths,
+            blank=blank,
+            fastemit_lambda=fastemit_lambda,
+            required_grad=enable_grad
+        )
+        if enable_grad:
+            cumlen = torch.cumsum(frames_lengths * (labels_lengths + 1), dim=0, dtype=torch.int32)
+            ctx.V = log_probs.size(-1)
+            ctx.blank = blank
+            ctx.save_for_backward(grads, loc, cumlen)
+        return costs
+
+    @staticmethod
+    def backward(ctx, grads_output):
+        grads, loc, cumlen = ctx.saved_tensors
+        grads_input = core.rnnt_loss_compact_backward(
+            grads_output.contiguous(),
+            grads, cumlen,
+            loc, ctx.V, ctx.blank
+        )
+        return grads_input, None, None, None, None, None, None
+
+
 def rnnt_loss(log_probs: torch.FloatTensor,
               labels: torch.IntTensor,
               frames_lengths: torch.IntTensor,
@@ -81,7 +112,8 @@ def rnnt_loss(log_probs: torch.FloatTensor,
         blank: index of the blank symbol.
         gather: run the lattice on the 2-channel (blank, label) view of ``log_probs``.
         fastemit_lambda: FastEmit regularisation weight (https://arxiv.org/abs/2010.11148).
-        compact: ragged packed layout (not built yet in this framework).
+        compact: ragged packed layout: log_probs (STU, V) with STU = sum(frames_lengths*(labels_lengths+1)),
+            labels (sum(labels_lengths),).
     """
     assert average_frames is None or isinstance(average_frames, bool)
     assert reduction is None or reduction in ("none", "mean", "sum")
@@ -93,10 +125,14 @@ def rnnt_loss(log_probs: torch.FloatTensor,
     assert not labels_lengths.requires_grad, "labels_lengths does not require gradients"
 
     if compact:
-        raise NotImplementedError(
-            "compact=True (ragged packed layout, core_compact.cu) is not built yet; "
-            "use gather=True for the low-memory path")
-    if gather:
+        costs = RNNTLossCompact.apply(
+            log_probs.float(),
+            labels, frames_lengths,
+            labels_lengths, blank,
+            fastemit_lambda,
+            (log_probs.requires_grad and torch.is_grad_enabled())
+        )
+    elif gather:
         costs = RNNTLossGather.apply(log_probs, labels, frames_lengths, labels_lengths, blank, fastemit_lambda)
     else:
         costs = RNNTLoss.apply(log_probs, labels, frames_lengths, labels_lengths, blank, fastemit_lambda)

@@ -153,6 +153,55 @@ rnntStatus_t rnnt_amd_debug_lattice_only(rnntStream_t stream, void* workspace, c
     return RNNT_STATUS_SUCCESS;
 }
 
+size_t rnnt_amd_workspace_size_compact(int N, int64_t STU) {
+    if (N < 0 || N > 65535 || STU < 0 || STU >= ((int64_t)1 << 32)) return 0;
+    return align_up((size_t)STU * 4) * 2 + align_up((size_t)STU * 8) + align_up((size_t)N * 4) * 2 + ALIGN;
+}
+
+// Compact (ragged packed) layout: replaces run_gather_for_compact + run_warp_rnnt_compact
+// (core.h:41-54, core_compact.cu:360-436) with the conventions of the rest of this ABI
+// (status codes, caller's stream, no exit(), no host synchronisation).
+rnntStatus_t rnnt_amd_loss_compact(rnntStream_t stream, void* workspace, const float* xs, const int* ys,
+                                   const int* xn, const int* yn, const int64_t* cell_offsets,
+                                   const int* label_offsets, float* costs, float* grads2, int64_t* loc,
+                                   int N, int64_t STU, int Tmax, int Umax, int V, int blank,
+                                   float fastemit_lambda) {
+    if (!dims_ok(N, Tmax > 0 ? Tmax : 1, Umax > 0 ? Umax : 1) || !workspace || V < 1 || blank < 0 || blank >= V)
+        return RNNT_STATUS_INVALID_ARGUMENT;
+    if (STU < 0 || STU >= ((int64_t)1 << 32)) return RNNT_STATUS_INVALID_ARGUMENT;
+    if (reinterpret_cast<uintptr_t>(workspace) % ALIGN) return RNNT_STATUS_INVALID_ARGUMENT;
+    if (N == 0 || STU == 0) return RNNT_STATUS_SUCCESS;
+    char* p = static_cast<char*>(workspace);
+    float* alphas = reinterpret_cast<float*>(p); p += align_up((size_t)STU * 4);
+    float* betas = reinterpret_cast<float*>(p); p += align_up((size_t)STU * 4);
+    float* ws2 = reinterpret_cast<float*>(p); p += align_up((size_t)STU * 8);
+    float* ll = reinterpret_cast<float*>(p); p += align_up((size_t)N * 4);
+    int* mismatch = reinterpret_cast<int*>(p);
+    if (launch_gather_compact(stream, xs, ys, xn, yn, cell_offsets, label_offsets, ws2, loc, N, Tmax, Umax, V,
+                              blank) != hipSuccess)
+        return RNNT_STATUS_PROLOGUE_FAILED;
+    LatticeArgs la{ws2, nullptr, xn, yn, alphas, betas, ll, Tmax, Umax, 2, 0, cell_offsets};
+    if (launch_lattice(stream, la, N, LOAD_SKEWED) != hipSuccess) return RNNT_STATUS_WARP_FAILED;
+    GradArgs ga{ws2, nullptr, xn, yn, alphas, betas, ll, grads2 ? grads2 : ws2, costs, mismatch,
+                Tmax, Umax, 2, 0, fastemit_lambda, cell_offsets};
+    if (launch_grads(stream, ga, N, LOAD_SKEWED, grads2 ? WRITE_ROWMAJOR2 : WRITE_SKEWED2) != hipSuccess)
+        return RNNT_STATUS_GRADS_BLANK_FAILED;
+    return RNNT_STATUS_SUCCESS;
+}
+
+// Replaces run_scatter_grad_for_compact (core.h:56-60, core_compact.cu:456-500): dense (STU,V)
+// gradient rows, fully written.  cum_lens = inclusive prefix sums of xn*(yn+1) (int32, as the
+// reference's RNNTLossCompact.forward builds them, __init__.py:38).
+rnntStatus_t rnnt_amd_compact_scatter_grads(rnntStream_t stream, const float* grad_costs,
+                                            const float* grads2, const int64_t* loc, const int* cum_lens,
+                                            float* dense_grads, int64_t STU, int N, int V, int blank) {
+    if (N < 0 || STU < 0 || V < 1 || blank < 0 || blank >= V) return RNNT_STATUS_INVALID_ARGUMENT;
+    if (launch_scatter_compact(stream, grad_costs, grads2, loc, cum_lens, dense_grads, STU, N, V, blank) !=
+        hipSuccess)
+        return RNNT_STATUS_EXPAND_FAILED;
+    return RNNT_STATUS_SUCCESS;
+}
+
 rnntStatus_t rnnt_amd_expand_grads(rnntStream_t stream, const float* grads_diagonal, const int* labels,
                                    const int* xn, const int* yn, const float* grad_costs,
                                    float* dense_grads, int N, int T, int U, int V, int blank,

@@ -20,10 +20,10 @@ namespace rnnt {
 
 template <int LOADER, int WRITER>
 __global__ void __launch_bounds__(256) k_grads(const GradArgs a) {
-    const int T = a.T, U = a.U;
     const int n = blockIdx.y;
     const int Tn = a.xn[n], Un = a.yn[n] + 1;
-    const size_t nb = (size_t)n * T * U;
+    const int T = a.offs ? Tn : a.T, U = a.offs ? Un : a.U;      // compact: per-utterance planes
+    const size_t nb = a.offs ? (size_t)a.offs[n] : (size_t)n * T * U;
     const float* __restrict__ al = a.alphas + nb;
     const float* __restrict__ be = a.betas + nb;
 

@@ -14,6 +14,8 @@ struct LatticeArgs {
     float* betas;         // (N,T,U) diagonal-major scratch (out)
     float* ll;            // (N,) alpha-side log-likelihood alpha[T-1,U-1]+lpB[T-1,U-1] (out)
     int T, U, V, blank;   // V/blank: LOAD_DENSE only
+    const int64_t* offs;  // compact layout: (N+1,) cell offset of each utterance's (T_n, U_n) plane;
+                          // nullptr = padded (N,T,U) planes
 };
 
 struct GradArgs {
@@ -29,6 +31,7 @@ struct GradArgs {
     int* mismatch;        // (N,) optional: 1 where the alpha/beta guard fired
     int T, U, V, blank;
     float fastemit_lambda;
+    const int64_t* offs;  // as LatticeArgs
 };
 
 hipError_t launch_lattice(hipStream_t stream, const LatticeArgs& a, int N, int loader);
@@ -39,6 +42,13 @@ hipError_t launch_log_softmax(hipStream_t stream, const float* x, float* out, in
 hipError_t launch_gather(hipStream_t stream, const float* log_probs, const int* labels, float* out2,
                          int N, int T, int U, int V, int blank, bool skewed);
 hipError_t launch_reskew(hipStream_t stream, const float* lp2_rowmajor, float* ws2, int N, int T, int U);
+// compact (ragged packed) layout, core_compact.cu:403-436,456-484
+hipError_t launch_gather_compact(hipStream_t stream, const float* xs, const int* ys, const int* xn,
+                                 const int* yn, const int64_t* offs, const int* label_offs, float* ws2,
+                                 int64_t* loc, int N, int Tmax, int Umax, int V, int blank);
+hipError_t launch_scatter_compact(hipStream_t stream, const float* grad_cost, const float* grads2,
+                                  const int64_t* loc, const int* cum_lens, float* out, int64_t STU, int N,
+                                  int V, int blank);
 hipError_t launch_log_softmax_gather_skewed(hipStream_t stream, const float* logits, const int* labels,
                                             float* ws2, int N, int T, int U, int V, int blank);
 hipError_t launch_expand(hipStream_t stream, const float* g2_skewed, const int* labels,

@@ -64,17 +64,17 @@ constexpr int OOB = (int)0x80000000;     // voffset beyond any num_records: load
 //   DENSE:     same, plus the label index of column u (lab < 0: no label, use blank).
 template <int LOADER>
 __device__ __forceinline__ Cell load_cell(const LatticeArgs& a, __amdgpu_buffer_rsrc_t rs, size_t nbase,
-                                          int row, int t, int u, int lab) {
+                                          int U, int row, int t, int u, int lab) {
     Cell c;
     if constexpr (LOADER == LOAD_SKEWED) {
         const f32x2 v = __builtin_bit_cast(
-            f32x2, __builtin_amdgcn_raw_buffer_load_b64(rs, u * 8, row * a.U * 8, 0));
+            f32x2, __builtin_amdgcn_raw_buffer_load_b64(rs, u * 8, row * U * 8, 0));
         c.b = v.x; c.l = v.y;
     } else if constexpr (LOADER == LOAD_ROWMAJOR2) {
-        const float2 v = reinterpret_cast<const float2*>(a.lp)[nbase + (size_t)t * a.U + u];
+        const float2 v = reinterpret_cast<const float2*>(a.lp)[nbase + (size_t)t * U + u];
         c.b = v.x; c.l = v.y;
     } else {
-        const float* p = a.lp + (nbase + (size_t)t * a.U + u) * (size_t)a.V;
+        const float* p = a.lp + (nbase + (size_t)t * U + u) * (size_t)a.V;
         c.b = p[a.blank];
         c.l = p[lab < 0 ? a.blank : lab];
     }
@@ -199,12 +199,13 @@ __device__ __forceinline__ void run_block(const Cell (&cur)[K], const float mvec
 template <int LOADER, bool BETA>
 __device__ __forceinline__ void sweep(const LatticeArgs& a, const int n, float (*mail)[RING],
                                       float (*trash)[MAIL_TRASH]) {
-    const int T = a.T, U = a.U;
     const int Tn = a.xn[n], Un = a.yn[n] + 1;
+    // padded planes (N,T,U), or -- compact layout -- one (T_n,U_n) plane per utterance at offs[n]
+    const int T = a.offs ? Tn : a.T, U = a.offs ? Un : a.U;
     const int lane = threadIdx.x & (WAVE - 1);
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform
     const int nw = blockDim.x >> 6;
-    const size_t nbase = (size_t)n * T * U;
+    const size_t nbase = a.offs ? (size_t)a.offs[n] : (size_t)n * T * U;
     float* out = (BETA ? a.betas : a.alphas) + nbase;
     const int ndiag = Tn + Un - 1;
     const float NEG_INF = -__builtin_inff();
@@ -272,7 +273,7 @@ __device__ __forceinline__ void sweep(const LatticeArgs& a, const int n, float (
                     const int tt = dblk * K + k - ucol;
                     t = min(max(BETA ? (Tn - 1 - tt) : tt, 0), T - 1);
                 }
-                dst[k] = load_cell<LOADER>(a, rs_lp, nbase, rows[k], t, uc, lab);
+                dst[k] = load_cell<LOADER>(a, rs_lp, nbase, U, rows[k], t, uc, lab);
             }
         };
         auto do_block = [&](const int lb, auto ph) {
@@ -297,7 +298,7 @@ __device__ __forceinline__ void sweep(const LatticeArgs& a, const int n, float (
                         if constexpr (!BETA) {
                             int labb = -1;
                             if constexpr (LOADER == LOAD_DENSE) labb = a.labels[(size_t)n * (U - 1) + ub];
-                            v += load_cell<LOADER>(a, rs_lp, nbase, rb, dd - (c0 - 1), ub, labb).l;
+                            v += load_cell<LOADER>(a, rs_lp, nbase, U, rb, dd - (c0 - 1), ub, labb).l;
                         }
                         mvec = v;
                     }

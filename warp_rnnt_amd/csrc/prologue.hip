@@ -371,4 +371,129 @@ hipError_t launch_reskew(hipStream_t stream, const float* lp2_rowmajor, float* w
     return launch_to_diagonal(stream, lp2_rowmajor, nullptr, ws2, N, T, U, 2, 0, false);
 }
 
+
+// ---------------------------------------------------------------------------
+// Compact (ragged packed) layout, reference: core_compact.cu:403-436 (gather) and
+// :456-484 (scatter backward).  log-probs are (STU, V) rows, utterance n owning
+// rows [offs[n], offs[n+1]) as a (T_n, U_n) row-major block; labels are packed (sum yn,).
+// The gather produces the diagonal-major pairs of each utterance's own (T_n,U_n) plane
+// (same 32x32 tile scheme as k_to_diagonal) plus `loc`, the vocabulary index the label
+// channel was taken from (blank on the last column), which the backward scatter needs.
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_gather_compact(const float* __restrict__ xs, const int* __restrict__ ys, const int* __restrict__ xn,
+                 const int* __restrict__ yn, const int64_t* __restrict__ offs,
+                 const int* __restrict__ label_offs, float2* __restrict__ ws2, int64_t* __restrict__ loc,
+                 int V, int blank, int tiles_t, int tiles_u) {
+    __shared__ float2 tile[TD][TD];
+    unsigned b = blockIdx.x;
+    const int tu = b % tiles_u; b /= tiles_u;
+    const int tt = b % tiles_t;
+    const int n = b / tiles_t;
+    const int T = xn[n], U = yn[n] + 1;
+    const int t0 = tt * TD, u0 = tu * TD;
+    if (t0 >= T || u0 >= U) return;                    // whole tile outside this utterance (uniform)
+    const int ul = threadIdx.x & (TD - 1), tl0 = threadIdx.x >> 5;
+    const int u = u0 + ul;
+    const size_t nbase = (size_t)offs[n];
+    int lab = blank;
+    if (u < U - 1) lab = ys[label_offs[n] + u];
+#pragma unroll
+    for (int k = 0; k < TD / 8; ++k) {
+        const int tl = tl0 + 8 * k, t = t0 + tl;
+        if (t < T && u < U) {
+            const size_t cell = nbase + (size_t)t * U + u;
+            const float* p = xs + cell * (size_t)V;
+            tile[tl][ul] = make_float2(p[blank], p[lab]);
+            if (loc) loc[cell] = lab;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < (2 * TD) / 8; ++k) {
+        const int d = tl0 + 8 * k;
+        const int tl = d - ul;
+        if (d < 2 * TD - 1 && tl >= 0 && tl < TD) {
+            const int t = t0 + tl;
+            if (t < T && u < U) {
+                int r = t + u;
+                r = r >= T ? r % T : r;
+                ws2[nbase + (size_t)r * U + u] = tile[tl][ul];
+            }
+        }
+    }
+}
+
+hipError_t launch_gather_compact(hipStream_t stream, const float* xs, const int* ys, const int* xn,
+                                 const int* yn, const int64_t* offs, const int* label_offs, float* ws2,
+                                 int64_t* loc, int N, int Tmax, int Umax, int V, int blank) {
+    if (N <= 0 || Tmax <= 0 || Umax <= 0) return hipSuccess;
+    const int tiles_t = (Tmax + TD - 1) / TD, tiles_u = (Umax + TD - 1) / TD;
+    const size_t nblk = (size_t)N * tiles_t * tiles_u;
+    if (nblk >= ((size_t)1 << 31)) return hipErrorInvalidValue;
+    k_gather_compact<<<(unsigned)nblk, 256, 0, stream>>>(xs, ys, xn, yn, offs, label_offs,
+                                                         reinterpret_cast<float2*>(ws2), loc, V, blank,
+                                                         tiles_t, tiles_u);
+    return hipGetLastError();
+}
+
+// scatter_grad[i, blank] = g[i,0]*grad_cost[n(i)];  if loc[i] != blank: scatter_grad[i, loc[i]] = g[i,1]*grad_cost[n(i)]
+// Every output row is written once in full (the reference zero-fills (STU,V) and then does two
+// scattered writes per row).  A workgroup owns 4096 consecutive floats of the output.
+template <int VEC>
+__global__ void __launch_bounds__(256)
+k_scatter_compact(const float* __restrict__ grad_cost, const float2* __restrict__ g2,
+                  const int64_t* __restrict__ loc, const int* __restrict__ cum_lens, float* __restrict__ out,
+                  int64_t total, int N, int V, int blank) {
+    const int64_t base = (int64_t)blockIdx.x * 256 * VEC;
+    const int64_t row0 = base / V;                      // one 64-bit division per workgroup
+    const unsigned el = (unsigned)(base - row0 * V) + threadIdx.x * VEC;
+    int64_t row = row0 + el / (unsigned)V;
+    int v = el % (unsigned)V;
+    if (base + (int64_t)threadIdx.x * VEC >= total) return;
+    float vals[VEC];
+    int64_t crow = -1;
+    float gB = 0.f, gL = 0.f;
+    int lab = -1;
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+        if (row != crow) {
+            crow = row;
+            // utterance of this row: first n with cum_lens[n] > row (inclusive prefix sums)
+            int lo = 0, hi = N - 1;
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if ((int64_t)cum_lens[mid] > row) hi = mid; else lo = mid + 1;
+            }
+            const float sc = grad_cost[lo];
+            const float2 g = g2[row];
+            gB = g.x * sc; gL = g.y * sc;
+            lab = (int)loc[row];
+        }
+        vals[j] = (v == blank) ? gB : ((v == lab) ? gL : 0.0f);
+        if (++v == V) { v = 0; ++row; }
+    }
+    float* dst = out + base + (int64_t)threadIdx.x * VEC;
+    if constexpr (VEC == 4) *reinterpret_cast<float4*>(dst) = make_float4(vals[0], vals[1], vals[2], vals[3]);
+    else dst[0] = vals[0];
+}
+
+hipError_t launch_scatter_compact(hipStream_t stream, const float* grad_cost, const float* grads2,
+                                  const int64_t* loc, const int* cum_lens, float* out, int64_t STU, int N,
+                                  int V, int blank) {
+    const int64_t total = STU * V;
+    if (total <= 0) return hipSuccess;
+    const bool vec = (total % 4 == 0) && (reinterpret_cast<uintptr_t>(out) % 16 == 0);
+    const int64_t per_block = vec ? 1024 : 256;
+    const int64_t nblk = (total + per_block - 1) / per_block;
+    if (nblk >= ((int64_t)1 << 31)) return hipErrorInvalidValue;
+    if (vec)
+        k_scatter_compact<4><<<(unsigned)nblk, 256, 0, stream>>>(grad_cost, reinterpret_cast<const float2*>(grads2),
+                                                                  loc, cum_lens, out, total, N, V, blank);
+    else
+        k_scatter_compact<1><<<(unsigned)nblk, 256, 0, stream>>>(grad_cost, reinterpret_cast<const float2*>(grads2),
+                                                                  loc, cum_lens, out, total, N, V, blank);
+    return hipGetLastError();
+}
+
 }  // namespace rnnt

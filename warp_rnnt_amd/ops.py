@@ -87,3 +87,57 @@ def gather(log_probs, labels, blank=0):
         _check(L.rnnt_amd_gather(_stream(log_probs.device), log_probs.data_ptr(), _ptr(labels),
                                  out.data_ptr(), N, T, U, V, blank))
     return out
+
+
+def loss_compact(xs, ys, xn, yn, blank=0, fastemit_lambda=0.0, required_grad=True):
+    """Compact (ragged packed) layout: xs (STU,V), ys (sum yn,), xn/yn (N,).
+    Returns (costs (N,), grads (STU,2) or None, loc (STU,) int64).  One host synchronisation
+    (max lengths for the launch geometry + the shape checks; the reference does four)."""
+    L = _lib.load()
+    dev = xs.device
+    N = xn.shape[0]
+    STU, V = xs.shape
+    with torch.cuda.device(dev):
+        costs = torch.empty((N,), dtype=torch.float32, device=dev)
+        loc = torch.empty((STU,), dtype=torch.int64, device=dev)
+        grads = torch.empty((STU, 2), dtype=torch.float32, device=dev) if required_grad else None
+        if N == 0:
+            return costs, grads, loc
+        cells = xn.to(torch.int64) * (yn.to(torch.int64) + 1)
+        offs = torch.zeros((N + 1,), dtype=torch.int64, device=dev)
+        torch.cumsum(cells, 0, out=offs[1:])
+        loffs = torch.zeros((N + 1,), dtype=torch.int32, device=dev)
+        torch.cumsum(yn, 0, out=loffs[1:])
+        stats = torch.stack([offs[-1], loffs[-1].to(torch.int64), xn.max().to(torch.int64),
+                             yn.max().to(torch.int64)]).tolist()          # the one host sync
+        stu_chk, su, tmax, umax = int(stats[0]), int(stats[1]), int(stats[2]), int(stats[3]) + 1
+        if ys.numel() != su:
+            raise RuntimeError("ys shape must be equal to (sum(yn), )")
+        if STU != stu_chk:
+            raise RuntimeError("xs shape mismatch with (\\sum{xn*(yn+1)}, )")
+        ws_bytes = L.rnnt_amd_workspace_size_compact(N, STU)
+        if ws_bytes == 0:
+            raise RuntimeError("rnnt_loss status 5 (RNNT_STATUS_INVALID_ARGUMENT): unsupported sizes")
+        ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
+        st = L.rnnt_amd_loss_compact(_stream(dev), ws.data_ptr(), xs.data_ptr(), _ptr(ys), xn.data_ptr(),
+                                     yn.data_ptr(), offs.data_ptr(), loffs.data_ptr(), costs.data_ptr(),
+                                     _ptr(grads), loc.data_ptr(), N, STU, tmax, umax, V, blank,
+                                     float(fastemit_lambda))
+        _check(st)
+    return costs, grads, loc
+
+
+def compact_scatter_grads(grad_cost, grad_xs, cum_lens, loc, V, blank):
+    """(STU,V) gradient rows from the (STU,2) pairs (reference: rnnt_loss_compact_backward)."""
+    L = _lib.load()
+    dev = grad_xs.device
+    STU = grad_xs.shape[0]
+    N = grad_cost.shape[0]
+    with torch.cuda.device(dev):
+        out = torch.empty((STU, V), dtype=torch.float32, device=dev)
+        if STU == 0:
+            return out
+        _check(L.rnnt_amd_compact_scatter_grads(_stream(dev), grad_cost.data_ptr(), grad_xs.data_ptr(),
+                                                loc.data_ptr(), cum_lens.data_ptr(), out.data_ptr(), STU, N,
+                                                int(V), int(blank)))
+    return out
