@@ -187,6 +187,30 @@ def main():
         extras["loss_only_ms"] = round(e0.elapsed_time(e1) / reps, 4)
         extras["fused_from_logits_ms"] = round(e1.elapsed_time(e2) / reps, 4)
         del lp
+        # full training step (forward + backward to d/d logits), reference-style chain vs fused entry
+        from warp_rnnt_amd.fused import rnnt_loss_from_logits
+        xg = xs.detach().clone().requires_grad_(True)
+
+        def chain():
+            xg.grad = None
+            warp_rnnt.rnnt_loss(torch.log_softmax(xg, -1), ys, xn, yn, gather=gather, fastemit_lambda=lam,
+                                reduction="sum").backward()
+
+        def fused():
+            xg.grad = None
+            rnnt_loss_from_logits(xg, ys, xn, yn, fastemit_lambda=lam, reduction="sum").backward()
+
+        for name, fn in (("train_step_torch_log_softmax_chain_ms", chain), ("train_step_fused_logits_ms", fused)):
+            fn()
+            torch.cuda.synchronize()
+            a0, a1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a0.record()
+            for _ in range(5):
+                fn()
+            a1.record()
+            torch.cuda.synchronize()
+            extras[name] = round(a0.elapsed_time(a1) / 5, 4)
+        del xg
 
     if rank == 0:
         value = world * N / (ms_step * 1e-3)

@@ -136,6 +136,17 @@ rnntStatus_t rnnt_amd_compact_scatter_grads(rnntStream_t stream, const float *gr
                                             const float *grads2, const int64_t *loc, const int *cum_lens,
                                             float *dense_grads, int64_t STU, int N, int V, int blank);
 
+/*
+ * Backward of rnnt_amd_loss(RNNT_IN_LOGITS_DENSE -> RNNT_GRADS_GATHERED_DIAGONAL): the gradient
+ * w.r.t. the LOGITS, dz[v] = s_n * ( [v==blank] gB + [v==label] gL - softmax(z)[v] (gB+gL) ), one
+ * read of the logits and one write of dlogits (dlogits may alias logits).  The log-probabilities
+ * and their dense gradient never exist in HBM (the caller-side chain
+ * F.log_softmax -> gather -> loss of benchmark.py:65-70 costs 28V bytes per cell, this 12V+8).
+ */
+rnntStatus_t rnnt_amd_logits_backward(rnntStream_t stream, const float *logits, const int *labels,
+                                      const float *grads_diagonal, const float *grad_costs, float *dlogits,
+                                      int N, int T, int U, int V, int blank);
+
 /* Row-wise log-softmax over the last axis; out may alias x. */
 rnntStatus_t rnnt_amd_log_softmax(rnntStream_t stream, const float *x, float *out, int64_t rows, int V);
 

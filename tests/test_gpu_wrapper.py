@@ -108,3 +108,30 @@ def test_non_default_stream_and_device_guard():
         tot = c.sum()
     s.synchronize()
     np.testing.assert_allclose(tot.item(), ref["costs"].sum(), rtol=1e-5)
+
+
+@pytest.mark.parametrize("N,Tm,Um,V", [(3, 30, 12, 50), (2, 9, 5, 5000), (2, 11, 70, 7), (2, 6, 4, 1030)])
+def test_fused_from_logits_forward_backward(N, Tm, Um, V):
+    """rnnt_loss_from_logits == rnnt_loss(torch.log_softmax(logits), gather=True) incl. d/d logits
+    (small-V, large-V and generic log-softmax kernels)."""
+    import warp_rnnt
+    from warp_rnnt_amd.fused import rnnt_loss_from_logits
+    logits, labels, xn, yn = make_case(5 + V, N, Tm, Um, V, ragged=True)
+    up = np.random.RandomState(0).rand(N).astype(np.float32) + 0.5
+    z1 = T(logits).requires_grad_(True)
+    l1 = warp_rnnt.rnnt_loss(torch.log_softmax(z1, -1), T(labels), T(xn), T(yn), gather=True,
+                             fastemit_lambda=0.01)
+    l1.backward(T(up))
+    z2 = T(logits).requires_grad_(True)
+    l2 = rnnt_loss_from_logits(z2, T(labels), T(xn), T(yn), fastemit_lambda=0.01)
+    l2.backward(T(up))
+    np.testing.assert_allclose(l2.detach().cpu().numpy(), l1.detach().cpu().numpy(), rtol=1e-5)
+    np.testing.assert_allclose(z2.grad.cpu().numpy(), z1.grad.cpu().numpy(), atol=2e-5)
+    # against exact arithmetic: dz = g - softmax * sum(g) with the fp64 oracle's g
+    from oracle import transduce_np
+    lp64 = transduce_np.log_softmax(logits)
+    c64, g64 = transduce_np.transduce_batch(lp64, labels, xn, yn, fastemit_lambda=0.01, fast=True)
+    g64 = g64 * up[:, None, None, None]
+    dz64 = g64 - np.exp(lp64) * g64.sum(-1, keepdims=True)
+    np.testing.assert_allclose(z2.grad.cpu().numpy(), dz64, atol=1e-4)
+    np.testing.assert_allclose(l2.detach().cpu().numpy(), c64, rtol=1e-5)

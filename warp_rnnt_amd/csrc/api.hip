@@ -215,6 +215,18 @@ rnntStatus_t rnnt_amd_expand_grads(rnntStream_t stream, const float* grads_diago
     return RNNT_STATUS_SUCCESS;
 }
 
+// Backward of the fused RNNT_IN_LOGITS_DENSE path: d(sum_n grad_costs[n]*cost[n]) / d(logits).
+rnntStatus_t rnnt_amd_logits_backward(rnntStream_t stream, const float* logits, const int* labels,
+                                      const float* grads_diagonal, const float* grad_costs, float* dlogits,
+                                      int N, int T, int U, int V, int blank) {
+    if (!dims_ok(N, T, U) || V < 1 || blank < 0 || blank >= V) return RNNT_STATUS_INVALID_ARGUMENT;
+    if (U > 1 && !labels) return RNNT_STATUS_INVALID_ARGUMENT;
+    if (launch_logits_backward(stream, logits, labels, grads_diagonal, grad_costs, dlogits, N, T, U, V, blank) !=
+        hipSuccess)
+        return RNNT_STATUS_EXPAND_FAILED;
+    return RNNT_STATUS_SUCCESS;
+}
+
 rnntStatus_t rnnt_amd_log_softmax(rnntStream_t stream, const float* x, float* out, int64_t rows, int V) {
     if (rows < 0 || V < 1) return RNNT_STATUS_INVALID_ARGUMENT;
     if (launch_log_softmax(stream, x, out, rows, V) != hipSuccess) return RNNT_STATUS_PROLOGUE_FAILED;

@@ -51,6 +51,9 @@ hipError_t launch_scatter_compact(hipStream_t stream, const float* grad_cost, co
                                   int V, int blank);
 hipError_t launch_log_softmax_gather_skewed(hipStream_t stream, const float* logits, const int* labels,
                                             float* ws2, int N, int T, int U, int V, int blank);
+hipError_t launch_logits_backward(hipStream_t stream, const float* logits, const int* labels,
+                                  const float* g2_diagonal, const float* scale, float* dlogits, int N, int T,
+                                  int U, int V, int blank);
 hipError_t launch_expand(hipStream_t stream, const float* g2_skewed, const int* labels,
                          const int* xn, const int* yn, const float* scale, float* dense, int N,
                          int T, int U, int V, int blank, int overwrite_mode);

@@ -37,6 +37,7 @@ __device__ __forceinline__ float group_sum(float v) {
 struct CellMap {
     size_t sk;   // float2 index into the workspace
     int label;   // vocabulary index of the label channel (blank for the last column)
+    int n;       // utterance
 };
 __device__ __forceinline__ CellMap map_cell(size_t cell, const int* __restrict__ labels, int T, int U,
                                             int blank) {
@@ -51,6 +52,7 @@ __device__ __forceinline__ CellMap map_cell(size_t cell, const int* __restrict__
     CellMap m;
     m.sk = ((size_t)n * T + r) * (size_t)U + u;
     m.label = (u < U - 1) ? labels[(size_t)n * (U - 1) + u] : blank;
+    m.n = (int)n;
     return m;
 }
 
@@ -67,6 +69,18 @@ __device__ __forceinline__ CellMap map_cell(size_t cell, const int* __restrict__
 //   v_exp_f32 unit, log(sum) as v_log_f32 * ln2 (sum in [1,V]); both are within
 //   ~2 ulp, the result is within 4e-6 of torch.log_softmax (tests).
 // ---------------------------------------------------------------------------
+// What the log-softmax kernels emit.
+enum LsmMode : int {
+    LSM_NORM = 0,    // log-softmax rows
+    LSM_GATHER = 1,  // diagonal-major (blank,label) log-prob pairs; log-probs never materialise
+    LSM_BWD = 2      // d(loss)/d(logits) rows from the gathered gradients:
+                     //   dz[v] = s*( [v==blank]gB + [v==label]gL - softmax(z)[v]*(gB+gL) )
+};
+struct LsmBwd {
+    const float2* g2;    // diagonal-major gathered gradients (RNNT_GRADS_GATHERED_DIAGONAL)
+    const float* scale;  // (N,) upstream gradient per utterance, or nullptr
+};
+
 constexpr int SM_THREADS = 256;
 #ifndef RNNT_SM_FLOATS
 #define RNNT_SM_FLOATS 3200
@@ -75,10 +89,11 @@ constexpr int SM_FLOATS = RNNT_SM_FLOATS;   // LDS tile budget in floats (12.5 K
 constexpr float LOG2E = 1.44269504088896340736f;
 constexpr float LN2 = 0.693147180559945309417f;
 
-template <int L, bool GATHER>
+template <int L, int MODE>
 __global__ void __launch_bounds__(SM_THREADS)
 k_lsm_small(const float* x, float* out, const int* __restrict__ labels,
-            int64_t rows, int V, int R, int q, int T, int U, int blank) {
+            int64_t rows, int V, int R, int q, int T, int U, int blank, LsmBwd bw) {
+    constexpr bool GATHER = MODE == LSM_GATHER;
     extern __shared__ __attribute__((aligned(16))) float tile[];
     const int tid = threadIdx.x;
     const int64_t row0 = (int64_t)blockIdx.x * R;
@@ -116,6 +131,17 @@ k_lsm_small(const float* x, float* out, const int* __restrict__ labels,
                 reinterpret_cast<float2*>(out)[m.sk] =
                     make_float2((row[blank] - mx) - ls, (row[m.label] - mx) - ls);
             }
+        } else if constexpr (MODE == LSM_BWD) {
+            const CellMap m = map_cell((size_t)(row0 + r), labels, T, U, blank);
+            const float sc = bw.scale ? bw.scale[m.n] : 1.0f;
+            const float2 g = bw.g2[m.sk];
+            const float gB = g.x * sc, gL = g.y * sc, gs = gB + gL;
+            const float mb2 = -(mx + ls) * LOG2E;
+            for (int i = 0, c = h; i < q - 1; ++i, c += L)
+                row[c] = -__builtin_amdgcn_exp2f(__builtin_fmaf(row[c], LOG2E, mb2)) * gs;
+            if (tail_ok) row[ctail] = -__builtin_amdgcn_exp2f(__builtin_fmaf(row[ctail], LOG2E, mb2)) * gs;
+            // the L lanes of a row sit in one wave and LDS operations of a wave retire in order
+            if (h == 0) { row[blank] += gB; row[m.label] += gL; }
         } else {
             for (int i = 0, c = h; i < q - 1; ++i, c += L) row[c] = (row[c] - mx) - ls;
             if (tail_ok) row[ctail] = (row[ctail] - mx) - ls;
@@ -150,10 +176,11 @@ __device__ __forceinline__ float block_reduce(float v, bool is_max, float* red) 
     return r;
 }
 
-template <bool GATHER>
+template <int MODE>
 __global__ void __launch_bounds__(LG_THREADS)
 k_lsm_large(const float* x, float* out, const int* __restrict__ labels,
-            int64_t rows, int V, int T, int U, int blank) {
+            int64_t rows, int V, int T, int U, int blank, LsmBwd bw) {
+    constexpr bool GATHER = MODE == LSM_GATHER;
     __shared__ float red[LG_THREADS / WAVE];
     for (size_t row = blockIdx.x; row < (size_t)rows; row += gridDim.x) {
     const float4* src = reinterpret_cast<const float4*>(x + row * V);
@@ -187,6 +214,29 @@ k_lsm_large(const float* x, float* out, const int* __restrict__ labels,
             reinterpret_cast<float2*>(out)[m.sk] =
                 make_float2((xr[blank] - mx) - ls, (xr[m.label] - mx) - ls);
         }
+    } else if constexpr (MODE == LSM_BWD) {
+        const CellMap m = map_cell(row, labels, T, U, blank);
+        const float sc = bw.scale ? bw.scale[m.n] : 1.0f;
+        const float2 g = bw.g2[m.sk];
+        const float gB = g.x * sc, gL = g.y * sc, gs = gB + gL;
+        const float mb2 = -(mx + ls) * LOG2E;
+        float4* dst = reinterpret_cast<float4*>(out + row * V);
+#pragma unroll
+        for (int i = 0; i < LG_MAXVEC; ++i) {
+            const int j = threadIdx.x + i * LG_THREADS;
+            if (j < nvec) {
+                float o[4] = {v[i].x, v[i].y, v[i].z, v[i].w};
+#pragma unroll
+                for (int cc = 0; cc < 4; ++cc) {
+                    const int e = 4 * j + cc;
+                    float d = -__builtin_amdgcn_exp2f(__builtin_fmaf(o[cc], LOG2E, mb2)) * gs;
+                    d += (e == blank) ? gB : 0.0f;
+                    d += (e == m.label) ? gL : 0.0f;
+                    o[cc] = d;
+                }
+                dst[j] = make_float4(o[0], o[1], o[2], o[3]);
+            }
+        }
     } else {
         float4* dst = reinterpret_cast<float4*>(out + row * V);
 #pragma unroll
@@ -203,10 +253,11 @@ k_lsm_large(const float* x, float* out, const int* __restrict__ labels,
 // ---------------------------------------------------------------------------
 // Generic fallback (any V, any alignment): one wave per row, three passes.
 // ---------------------------------------------------------------------------
-template <bool GATHER>
+template <int MODE>
 __global__ void __launch_bounds__(256)
 k_lsm_generic(const float* x, float* out, const int* __restrict__ labels,
-              int64_t rows, int V, int T, int U, int blank) {
+              int64_t rows, int V, int T, int U, int blank, LsmBwd bw) {
+    constexpr bool GATHER = MODE == LSM_GATHER;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     const int lane = threadIdx.x & 63;
@@ -224,15 +275,28 @@ k_lsm_generic(const float* x, float* out, const int* __restrict__ labels,
             reinterpret_cast<float2*>(out)[m.sk] =
                 make_float2((xr[blank] - mx) - ls, (xr[m.label] - mx) - ls);
         }
+    } else if constexpr (MODE == LSM_BWD) {
+        const CellMap m = map_cell((size_t)row, labels, T, U, blank);
+        const float sc = bw.scale ? bw.scale[m.n] : 1.0f;
+        const float2 g = bw.g2[m.sk];
+        const float gB = g.x * sc, gL = g.y * sc, gs = gB + gL;
+        float* o = out + row * V;
+        for (int c = lane; c < V; c += WAVE) {
+            float d = -expf((xr[c] - mx) - ls) * gs;
+            d += (c == blank) ? gB : 0.0f;
+            d += (c == m.label) ? gL : 0.0f;
+            o[c] = d;
+        }
     } else {
         float* o = out + row * V;
         for (int c = lane; c < V; c += WAVE) o[c] = (xr[c] - mx) - ls;
     }
 }
 
-template <bool GATHER>
+template <int MODE>
 static hipError_t dispatch_lsm(hipStream_t stream, const float* x, float* out, const int* labels,
-                               int64_t rows, int V, int T, int U, int blank) {
+                               int64_t rows, int V, int T, int U, int blank, LsmBwd bw) {
+    constexpr bool GATHER = MODE == LSM_GATHER;
     if (rows <= 0) return hipSuccess;
     const bool aligned = (reinterpret_cast<uintptr_t>(x) % 16 == 0) &&
                          (GATHER || reinterpret_cast<uintptr_t>(out) % 16 == 0);
@@ -247,8 +311,8 @@ static hipError_t dispatch_lsm(hipStream_t stream, const float* x, float* out, c
         const unsigned grid = (unsigned)((rows + R - 1) / R);
 #define LSM_SMALL(LL)                                                                           \
     case LL:                                                                                    \
-        k_lsm_small<LL, GATHER><<<grid, SM_THREADS, lds, stream>>>(x, out, labels, rows, V, R, q, T, \
-                                                                    U, blank);                  \
+        k_lsm_small<LL, MODE><<<grid, SM_THREADS, lds, stream>>>(x, out, labels, rows, V, R, q, T, U,  \
+                                                                  blank, bw);                   \
         break;
         switch (L) {
             LSM_SMALL(1) LSM_SMALL(2) LSM_SMALL(4) LSM_SMALL(8) LSM_SMALL(16) LSM_SMALL(32)
@@ -256,22 +320,30 @@ static hipError_t dispatch_lsm(hipStream_t stream, const float* x, float* out, c
         }
 #undef LSM_SMALL
     } else if (aligned && V % 4 == 0 && V <= LG_THREADS * 4 * LG_MAXVEC) {
-        k_lsm_large<GATHER><<<(unsigned)(rows < (1 << 22) ? rows : (1 << 22)), LG_THREADS, 0, stream>>>(
-            x, out, labels, rows, V, T, U, blank);
+        k_lsm_large<MODE><<<(unsigned)(rows < (1 << 22) ? rows : (1 << 22)), LG_THREADS, 0, stream>>>(
+            x, out, labels, rows, V, T, U, blank, bw);
     } else {
-        k_lsm_generic<GATHER><<<(unsigned)((rows + 3) / 4), 256, 0, stream>>>(x, out, labels, rows, V,
-                                                                               T, U, blank);
+        k_lsm_generic<MODE><<<(unsigned)((rows + 3) / 4), 256, 0, stream>>>(x, out, labels, rows, V, T,
+                                                                             U, blank, bw);
     }
     return hipGetLastError();
 }
 
 hipError_t launch_log_softmax(hipStream_t stream, const float* x, float* out, int64_t rows, int V) {
-    return dispatch_lsm<false>(stream, x, out, nullptr, rows, V, 1, 1, 0);
+    return dispatch_lsm<LSM_NORM>(stream, x, out, nullptr, rows, V, 1, 1, 0, LsmBwd{nullptr, nullptr});
 }
 
 hipError_t launch_log_softmax_gather_skewed(hipStream_t stream, const float* logits, const int* labels,
                                             float* ws2, int N, int T, int U, int V, int blank) {
-    return dispatch_lsm<true>(stream, logits, ws2, labels, (int64_t)N * T * U, V, T, U, blank);
+    return dispatch_lsm<LSM_GATHER>(stream, logits, ws2, labels, (int64_t)N * T * U, V, T, U, blank,
+                                    LsmBwd{nullptr, nullptr});
+}
+
+hipError_t launch_logits_backward(hipStream_t stream, const float* logits, const int* labels,
+                                  const float* g2_diagonal, const float* scale, float* dlogits, int N, int T,
+                                  int U, int V, int blank) {
+    return dispatch_lsm<LSM_BWD>(stream, logits, dlogits, labels, (int64_t)N * T * U, V, T, U, blank,
+                                 LsmBwd{reinterpret_cast<const float2*>(g2_diagonal), scale});
 }
 
 // ---------------------------------------------------------------------------

@@ -141,3 +141,19 @@ def compact_scatter_grads(grad_cost, grad_xs, cum_lens, loc, V, blank):
                                                 loc.data_ptr(), cum_lens.data_ptr(), out.data_ptr(), STU, N,
                                                 int(V), int(blank)))
     return out
+
+
+def logits_backward(logits, labels, grads_diagonal, grad_costs, blank=0, out=None):
+    """d(sum_n grad_costs[n]*cost[n]) / d(logits) for the fused RNNT_IN_LOGITS_DENSE path."""
+    L = _lib.load()
+    N, T, U, V = logits.shape
+    dev = logits.device
+    with torch.cuda.device(dev):
+        if out is None:
+            out = torch.empty_like(logits)
+        if N == 0:
+            return out
+        _check(L.rnnt_amd_logits_backward(_stream(dev), logits.data_ptr(), _ptr(labels),
+                                          grads_diagonal.data_ptr(), _ptr(grad_costs), out.data_ptr(),
+                                          N, T, U, V, blank))
+    return out
