@@ -76,8 +76,9 @@ def main():
     if os.path.exists(pre):
         L = ctypes.CDLL(pre)
         for sym, (res, a_) in _lib.SYMBOLS.items():
-            fn = getattr(L, sym)
-            fn.restype, fn.argtypes = res, a_
+            if hasattr(L, sym):
+                fn = getattr(L, sym)
+                fn.restype, fn.argtypes = res, a_
     else:
         L = build_variant(name, flags)
     stream = torch.cuda.current_stream().cuda_stream

@@ -18,12 +18,12 @@
 
 namespace rnnt {
 
-template <int LOADER, int WRITER>
+template <int LOADER, int WRITER, bool COMPACT>
 __global__ void __launch_bounds__(256) k_grads(const GradArgs a) {
     const int n = blockIdx.y;
     const int Tn = a.xn[n], Un = a.yn[n] + 1;
-    const int T = a.offs ? Tn : a.T, U = a.offs ? Un : a.U;      // compact: per-utterance planes
-    const size_t nb = a.offs ? (size_t)a.offs[n] : (size_t)n * T * U;
+    const int T = COMPACT ? Tn : a.T, U = COMPACT ? Un : a.U;     // compact: per-utterance planes
+    const size_t nb = COMPACT ? (size_t)a.offs[n] : (size_t)n * T * U;
     const float* __restrict__ al = a.alphas + nb;
     const float* __restrict__ be = a.betas + nb;
 
@@ -94,9 +94,9 @@ __global__ void __launch_bounds__(256) k_grads(const GradArgs a) {
 template <int LOADER>
 static hipError_t launch_grads_w(hipStream_t stream, const GradArgs& a, dim3 grid, int writer) {
     switch (writer) {
-        case WRITE_SKEWED2:   k_grads<LOADER, WRITE_SKEWED2><<<grid, 256, 0, stream>>>(a); break;
-        case WRITE_ROWMAJOR2: k_grads<LOADER, WRITE_ROWMAJOR2><<<grid, 256, 0, stream>>>(a); break;
-        default:              k_grads<LOADER, WRITE_DENSE_SLOTS><<<grid, 256, 0, stream>>>(a); break;
+        case WRITE_SKEWED2:   k_grads<LOADER, WRITE_SKEWED2, false><<<grid, 256, 0, stream>>>(a); break;
+        case WRITE_ROWMAJOR2: k_grads<LOADER, WRITE_ROWMAJOR2, false><<<grid, 256, 0, stream>>>(a); break;
+        default:              k_grads<LOADER, WRITE_DENSE_SLOTS, false><<<grid, 256, 0, stream>>>(a); break;
     }
     return hipGetLastError();
 }
@@ -104,6 +104,13 @@ static hipError_t launch_grads_w(hipStream_t stream, const GradArgs& a, dim3 gri
 hipError_t launch_grads(hipStream_t stream, const GradArgs& a, int N, int loader, int writer) {
     if (N <= 0) return hipSuccess;
     const dim3 grid(((unsigned)(a.T * a.U) + 255u) / 256u, (unsigned)N);
+    if (a.offs) {   // compact layout (a.T, a.U = maxima): diagonal-major pairs in, packed pairs out
+        if (writer == WRITE_ROWMAJOR2)
+            k_grads<LOAD_SKEWED, WRITE_ROWMAJOR2, true><<<grid, 256, 0, stream>>>(a);
+        else
+            k_grads<LOAD_SKEWED, WRITE_SKEWED2, true><<<grid, 256, 0, stream>>>(a);
+        return hipGetLastError();
+    }
     switch (loader) {
         case LOAD_SKEWED:    return launch_grads_w<LOAD_SKEWED>(stream, a, grid, writer);
         case LOAD_ROWMAJOR2: return launch_grads_w<LOAD_ROWMAJOR2>(stream, a, grid, writer);

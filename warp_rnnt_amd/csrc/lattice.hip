@@ -196,16 +196,16 @@ __device__ __forceinline__ void run_block(const Cell (&cur)[K], const float mvec
 #undef RNNT_PIN
 }
 
-template <int LOADER, bool BETA>
+template <int LOADER, bool BETA, bool COMPACT>
 __device__ __forceinline__ void sweep(const LatticeArgs& a, const int n, float (*mail)[RING],
                                       float (*trash)[MAIL_TRASH]) {
     const int Tn = a.xn[n], Un = a.yn[n] + 1;
     // padded planes (N,T,U), or -- compact layout -- one (T_n,U_n) plane per utterance at offs[n]
-    const int T = a.offs ? Tn : a.T, U = a.offs ? Un : a.U;
+    const int T = COMPACT ? Tn : a.T, U = COMPACT ? Un : a.U;
     const int lane = threadIdx.x & (WAVE - 1);
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform
     const int nw = blockDim.x >> 6;
-    const size_t nbase = a.offs ? (size_t)a.offs[n] : (size_t)n * T * U;
+    const size_t nbase = COMPACT ? (size_t)a.offs[n] : (size_t)n * T * U;
     float* out = (BETA ? a.betas : a.alphas) + nbase;
     const int ndiag = Tn + Un - 1;
     const float NEG_INF = -__builtin_inff();
@@ -392,15 +392,15 @@ __device__ __forceinline__ void sweep(const LatticeArgs& a, const int n, float (
     for (int c0 = blockDim.x; c0 < Un; c0 += blockDim.x) stripe(std::false_type{}, c0);
 }
 
-template <int LOADER>
+template <int LOADER, bool COMPACT>
 __global__ void __launch_bounds__(MAXW * WAVE) k_lattice(const LatticeArgs a) {
     __shared__ float mail[MAXW][RING];
     __shared__ float trash[MAXW][MAIL_TRASH];
     const int n = blockIdx.x >> 1;
     if (blockIdx.x & 1)
-        sweep<LOADER, true>(a, n, mail, trash);
+        sweep<LOADER, true, COMPACT>(a, n, mail, trash);
     else
-        sweep<LOADER, false>(a, n, mail, trash);
+        sweep<LOADER, false, COMPACT>(a, n, mail, trash);
 }
 
 hipError_t launch_lattice(hipStream_t stream, const LatticeArgs& a, int N, int loader) {
@@ -408,10 +408,14 @@ hipError_t launch_lattice(hipStream_t stream, const LatticeArgs& a, int N, int l
     int waves = (a.U + WAVE - 1) / WAVE;
     waves = waves < 1 ? 1 : (waves > MAXW ? MAXW : waves);
     const dim3 grid(2 * N), block(waves * WAVE);
+    if (a.offs) {   // compact layout: only the diagonal-major loader is used
+        k_lattice<LOAD_SKEWED, true><<<grid, block, 0, stream>>>(a);
+        return hipGetLastError();
+    }
     switch (loader) {
-        case LOAD_SKEWED:    k_lattice<LOAD_SKEWED><<<grid, block, 0, stream>>>(a); break;
-        case LOAD_ROWMAJOR2: k_lattice<LOAD_ROWMAJOR2><<<grid, block, 0, stream>>>(a); break;
-        default:             k_lattice<LOAD_DENSE><<<grid, block, 0, stream>>>(a); break;
+        case LOAD_SKEWED:    k_lattice<LOAD_SKEWED, false><<<grid, block, 0, stream>>>(a); break;
+        case LOAD_ROWMAJOR2: k_lattice<LOAD_ROWMAJOR2, false><<<grid, block, 0, stream>>>(a); break;
+        default:             k_lattice<LOAD_DENSE, false><<<grid, block, 0, stream>>>(a); break;
     }
     return hipGetLastError();
 }
