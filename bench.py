@@ -90,8 +90,20 @@ def cpu_baseline(cfg, utts):
         if (dt > 10.0 and reps >= 2) or reps >= 200 or dt > 30.0:
             break
     utts_total = utts * reps
-    return {"value": round(utts_total / dt, 3), "unit": "utterances/s", "cores": oracle.num_threads(),
-            "kind": "port",
+    # single-thread figure on a smaller sample (2 utterances, one pass)
+    nthreads = oracle.num_threads()
+    oracle.set_threads(1)
+    xs1, ys1, xn1, yn1 = xs[:2], ys[:2], xn[:2], yn[:2]
+    t1 = time.perf_counter()
+    lp1 = oracle.log_softmax_f32(xs1)
+    if gather:
+        oracle.rnnt_loss_f32(oracle.gather_f32(lp1, ys1, 0), ys1, xn1, yn1, blank=-1, fastemit_lambda=lam, scan_mode=1)
+    else:
+        oracle.rnnt_loss_f32(lp1, ys1, xn1, yn1, blank=0, fastemit_lambda=lam, scan_mode=1)
+    one_thread = len(xs1) / (time.perf_counter() - t1)
+    oracle.set_threads(nthreads)
+    return {"value": round(utts_total / dt, 3), "unit": "utterances/s", "cores": nthreads,
+            "kind": "port", "value_1_thread": round(one_thread, 3),
             "sample": f"{reps} passes over {utts} utterances of T={T},U={U},V={V} "
                       f"(log_softmax + gather + loss + grads), {dt:.2f} s wall, OpenMP over rows/utterances"}
 
@@ -239,7 +251,7 @@ def main():
                          "algorithmic_bytes": alg_bytes, "kernel_ms": round(k_ms, 4)},
         }
         out.update(extras)
-        if not a.no_cpu_baseline:
+        if not a.no_cpu_baseline and world == 1:   # the CPU leg is reported at N=1 only
             utts = a.cpu_utts or (16 if a.config in ("c2", "c4") else 4)
             if a.config == "c5":
                 out["cpu_baseline"] = None

@@ -50,6 +50,8 @@ def lib():
         L.oracle_gather.restype = None
         L.oracle_gather.argtypes = [fp, ip, fp] + [ctypes.c_int] * 5
         L.oracle_num_threads.restype = ctypes.c_int
+        L.oracle_set_threads.restype = None
+        L.oracle_set_threads.argtypes = [ctypes.c_int]
         _lib = L
     return _lib
 
@@ -112,3 +114,7 @@ def gather_f32(log_probs, labels, blank=0):
 
 def num_threads():
     return int(lib().oracle_num_threads())
+
+
+def set_threads(n):
+    lib().oracle_set_threads(int(n))

@@ -69,6 +69,23 @@ __device__ __forceinline__ CellMap map_cell(size_t cell, const int* __restrict__
 //   v_exp_f32 unit, log(sum) as v_log_f32 * ln2 (sum in [1,V]); both are within
 //   ~2 ulp, the result is within 4e-6 of torch.log_softmax (tests).
 // ---------------------------------------------------------------------------
+#ifdef RNNT_LSM_NT
+typedef float rnnt_f4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 rnnt_nt_load(const float4* p) {
+    rnnt_f4 v = __builtin_nontemporal_load(reinterpret_cast<const rnnt_f4*>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void rnnt_nt_store(float4* p, float4 v) {
+    rnnt_f4 w = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(w, reinterpret_cast<rnnt_f4*>(p));
+}
+#define RNNT_LSM_LOAD(p) rnnt_nt_load(p)
+#define RNNT_LSM_STORE(p, v) rnnt_nt_store(p, v)
+#else
+#define RNNT_LSM_LOAD(p) (*(p))
+#define RNNT_LSM_STORE(p, v) (*(p) = (v))
+#endif
+
 // What the log-softmax kernels emit.
 enum LsmMode : int {
     LSM_NORM = 0,    // log-softmax rows
@@ -104,7 +121,7 @@ k_lsm_small(const float* x, float* out, const int* __restrict__ labels,
     // ---- stage: the tile is a plain copy of the chunk ----
     const int nvec = nel >> 2;
     for (int i = tid; i < nvec; i += SM_THREADS)
-        reinterpret_cast<float4*>(tile)[i] = reinterpret_cast<const float4*>(src)[i];
+        reinterpret_cast<float4*>(tile)[i] = RNNT_LSM_LOAD(reinterpret_cast<const float4*>(src) + i);
     for (int e = (nvec << 2) + tid; e < nel; e += SM_THREADS) tile[e] = src[e];   // last chunk only
     __syncthreads();
 
@@ -151,7 +168,7 @@ k_lsm_small(const float* x, float* out, const int* __restrict__ labels,
         __syncthreads();
         float* dst = out + row0 * V;
         for (int i = tid; i < nvec; i += SM_THREADS)
-            reinterpret_cast<float4*>(dst)[i] = reinterpret_cast<const float4*>(tile)[i];
+            RNNT_LSM_STORE(reinterpret_cast<float4*>(dst) + i, reinterpret_cast<const float4*>(tile)[i]);
         for (int e = (nvec << 2) + tid; e < nel; e += SM_THREADS) dst[e] = tile[e];
     }
 }
@@ -356,13 +373,18 @@ hipError_t launch_logits_backward(hipStream_t stream, const float* logits, const
 // write amplification: rocprofv3 WRITE_SIZE 268 MB for a 57.6 MB output.)
 // ---------------------------------------------------------------------------
 constexpr int TD = 32;   // tile edge
+#ifndef RNNT_GATHER_REVERSE
+#define RNNT_GATHER_REVERSE 0
+#endif
 
 template <bool DENSE>
 __global__ void __launch_bounds__(256)
 k_to_diagonal(const float* __restrict__ src, const int* __restrict__ labels, float2* __restrict__ ws2,
               int T, int U, int V, int blank, int tiles_t, int tiles_u) {
     __shared__ float2 tile[TD][TD];
-    unsigned b = blockIdx.x;
+    // (probe knob: walking the tensor back to front to catch the producer's tail in L2/MALL
+    //  measured no gain at 1.44 GB)
+    unsigned b = RNNT_GATHER_REVERSE ? gridDim.x - 1 - blockIdx.x : blockIdx.x;
     const int tu = b % tiles_u; b /= tiles_u;
     const int tt = b % tiles_t;
     const int n = b / tiles_t;
