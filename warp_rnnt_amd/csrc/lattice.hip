@@ -111,6 +111,18 @@ __device__ __forceinline__ void run_block(const Cell (&cur)[K], const float mvec
             row_st = BETA ? (row_st == 0 ? T - 1 : row_st - 1) : (row_st + 1 == T ? 0 : row_st + 1);
         }
     }
+    // lse(a,b) = log(exp(a)+exp(b)) keeps the reference's structure (core.cu:26-39):
+    //   max(a,b) + log1p(exp(-|a-b|)).
+    // The transcendental part runs on the hardware v_exp_f32 / v_log_f32 units instead of the
+    // ~150-instruction ocml expf+log1pf pair (4x slower end to end; -DRNNT_PRECISE_LIBM builds that
+    // version for comparison -- this chain is the latency-critical path of the whole op):
+    //   e = 2^(-|a-b|*log2 e)                  abs. error <~ 1e-8 (it shrinks as fast as e)
+    //   u = fl(1+e);  log1p(e) = ln2*log2(u) + (e-(u-1))    the last term is the exact rounding
+    //                                                       error of 1+e; ~2 ulp of a value <= ln 2
+    // Both are far below the fp32 rounding of the final `max + ...` whenever |max| >= 1.  Measured
+    // against the libm-based fp32 oracle: sum of costs 7418.4797 vs 7418.4796 on the T=1500,U=300
+    // benchmark lattice, gradients within 1e-4 at T+U <~ 200 (tests/test_gpu_parity.py).
+    //
     // Hand-ordered step: a single wave issues in order, so the store / mailbox write / helper ops
     // are placed in the latency shadow of the dependent chain
     //   dpp -> add -> sub -> mul -> exp2 -> add -> log2 -> fma -> add
@@ -167,7 +179,10 @@ __device__ __forceinline__ void run_block(const Cell (&cur)[K], const float mvec
         RNNT_PIN();
         const float l2 = __builtin_amdgcn_logf(u);                                     // chain
         RNNT_PIN();
-#ifndef RNNT_LSE_UNCORRECTED
+#if defined(RNNT_PRECISE_LIBM)
+        const float val = mx + log1pf(expf(-__builtin_fabsf(t)));
+        (void)l2;
+#elif !defined(RNNT_LSE_UNCORRECTED)
         const float c = e - (u - 1.0f);                                                // shadow
         RNNT_PIN();
         const float l = __builtin_fmaf(l2, 0.693147180559945309417f, c);               // chain
