@@ -35,6 +35,8 @@ struct GradArgs {
 };
 
 hipError_t launch_lattice(hipStream_t stream, const LatticeArgs& a, int N, int loader);
+// wave-specialised variant (diagonal-major loader only); hipErrorNotSupported when U > 512
+hipError_t launch_lattice_ws(hipStream_t stream, const LatticeArgs& a, int N);
 hipError_t launch_grads(hipStream_t stream, const GradArgs& a, int N, int loader, int writer);
 
 // prologue / epilogue streaming kernels

@@ -420,6 +420,13 @@ __global__ void __launch_bounds__(MAXW * WAVE) k_lattice(const LatticeArgs a) {
 
 hipError_t launch_lattice(hipStream_t stream, const LatticeArgs& a, int N, int loader) {
     if (N <= 0) return hipSuccess;
+#ifndef RNNT_LATTICE_LEGACY
+    if (loader == LOAD_SKEWED) {
+        // preferred: compute / I/O wave pairs (lattice_ws.hip); one pass covers U <= 512
+        const hipError_t e = launch_lattice_ws(stream, a, N);
+        if (e != hipErrorNotSupported) return e;
+    }
+#endif
     int waves = (a.U + WAVE - 1) / WAVE;
     waves = waves < 1 ? 1 : (waves > MAXW ? MAXW : waves);
     const dim3 grid(2 * N), block(waves * WAVE);

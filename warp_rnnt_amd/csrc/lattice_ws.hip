@@ -1,0 +1,330 @@
+// Wave-specialised alpha / beta lattice sweep for MI355X (gfx950), diagonal-major layout.
+//
+// Same maths and the same anti-diagonal / DPP scheme as lattice.hip (read its header first);
+// what changes is WHO issues the memory instructions.  Measured on MI355X (rocprofv3 SQ
+// counters, tools/ubench/issue_cost.hip): a lone wave issues one instruction every ~4.5 cycles
+// whatever its type, so the per-diagonal cost of the sweep is the NUMBER of instructions the
+// computing wave executes (26 in lattice.hip: 15 VALU + loads, stores, row-offset SALU, branches)
+// plus the time it sits in s_waitcnt behind its own loads and stores.  Here every 64-column
+// block of the lattice gets two waves:
+//   * a COMPUTE wave that touches only registers and LDS: per diagonal one ds_read_b64 of the
+//     (blank,label) pair (prefetched a block ahead), the DPP shift, the lse chain, one
+//     ds_write_b32 of the result (+ one for the hand-over to the next column block);
+//   * an I/O wave on another SIMD of the same CU that streams the pairs HBM -> registers -> LDS
+//     two blocks ahead and the results LDS -> HBM one block behind, with all the row-offset
+//     arithmetic, liveness predicates and vmcnt waits.
+// One s_barrier per block of 8 diagonals orders both hand-overs (pairs: I/O -> compute, values:
+// compute -> I/O) and the column-block boundary mailbox.  LDS rings: pairs 3 slots, values 2.
+//
+// Timeline in global blocks g (every wave executes exactly G barriers), column block `idx`,
+// local time p = g - idx - SHIFT:
+//   I/O wave   at p: loads pairs(p+2) HBM -> registers ; writes pairs(p) registers -> LDS ;
+//                    stores values(p-3) LDS -> HBM
+//   compute    at p: computes local block lb = p-2 (its pairs were read from LDS during p-1),
+//                    prefetches pairs(lb+1) from LDS, writes values(lb) to LDS
+#include <type_traits>
+
+#include "common.h"
+#include "kernels.h"
+
+namespace rnnt {
+
+namespace ws {
+
+constexpr int K = 8;             // diagonals per block
+constexpr int RING = 4 * K;      // mailbox ring entries per column-block boundary
+constexpr int MAXA = 8;          // compute waves per workgroup (=> 512 columns per pass)
+constexpr int PSLOTS = 3;        // LDS ring of pair blocks
+constexpr int VSLOTS = 2;        // LDS ring of value blocks
+constexpr int DLOAD = 2;         // I/O wave loads pairs this many blocks before it writes them to LDS
+constexpr int NBR = DLOAD + 1;   // its register ring
+constexpr int SHIFT = DLOAD;     // global block g = local time + idx + SHIFT, so the first load is at g >= 0
+constexpr int TRASH = WAVE + K;
+constexpr int RSRC_WORD3 = 0x00020000;
+constexpr int OOB = (int)0x80000000;
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+struct Smem {   // per column block
+    f32x2 pairs[PSLOTS][K][WAVE];
+    float vals[VSLOTS][K][WAVE];
+    float mail[RING];
+    float trash[TRASH];
+};
+
+__device__ __forceinline__ void block_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
+// K diagonals of the compute wave.  cur = this block's pairs (registers).  Values go to LDS.
+template <bool BETA, bool MASKED, bool MAIL>
+__device__ __forceinline__ void compute_block(const f32x2 (&cur)[K], const float mvec, float& Y, float& X,
+                                              const int d0, const int ucol_chk, const int Tn,
+                                              float* vslot /* [K][WAVE] + lane */, float* mail_slot) {
+    float first[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) first[k] = readlane(mvec, k);
+#define RNNT_PIN() __builtin_amdgcn_sched_barrier(0)
+    // The LDS writes of step k (value, hand-over) are issued right AFTER the DPP of step k+1, in
+    // its latency shadow, instead of between the value and the DPP that depends on it.
+    float pval = 0.0f, pX = 0.0f;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const float left = wave_shr1(first[k], X);                                     // chain
+        RNNT_PIN();
+        if (k > 0) {
+#ifndef RNNT_WS_NOVAL
+            vslot[(k - 1) * WAVE] = pval;
+#endif
+            if constexpr (MAIL) mail_slot[k - 1] = pX;
+            RNNT_PIN();
+        }
+        float skip, emit;
+        if constexpr (BETA) { skip = Y + cur[k].x; emit = left + cur[k].y; }           // chain
+        else { skip = Y; emit = left; }
+        RNNT_PIN();
+        // lse(skip, emit) = max + log1p(exp(-|skip-emit|)), see lattice.hip
+        const float t = skip - emit;                                                   // chain
+        RNNT_PIN();
+        float mx;
+        asm("v_max_f32 %0, %1, %2" : "=v"(mx) : "v"(skip), "v"(emit));                 // shadow
+        RNNT_PIN();
+        const float m = -__builtin_fabsf(t) * 1.44269504088896340736f;                 // chain
+        RNNT_PIN();
+        const float e = __builtin_amdgcn_exp2f(m);                                     // chain
+        RNNT_PIN();
+        const float u = 1.0f + e;                                                      // chain
+        RNNT_PIN();
+        const float l2 = __builtin_amdgcn_logf(u);                                     // chain
+        RNNT_PIN();
+        const float c = e - (u - 1.0f);                                                // shadow
+        RNNT_PIN();
+        const float l = __builtin_fmaf(l2, 0.693147180559945309417f, c);               // chain
+        RNNT_PIN();
+        const float val = mx + l;                                                      // chain
+        RNNT_PIN();
+        float Yn, Xn;
+        if constexpr (BETA) { Yn = val; Xn = val; }
+        else { Xn = val + cur[k].y; RNNT_PIN(); Yn = val + cur[k].x; }
+        if constexpr (MASKED) {
+            const bool live = (unsigned)(d0 + k - ucol_chk) < (unsigned)Tn;
+            Y = live ? Yn : Y;
+            X = live ? Xn : X;
+        } else {
+            Y = Yn; X = Xn;
+        }
+        pval = val; pX = X;
+        RNNT_PIN();
+    }
+#ifndef RNNT_WS_NOVAL
+    vslot[(K - 1) * WAVE] = pval;
+#endif
+    if constexpr (MAIL) mail_slot[K - 1] = pX;
+#undef RNNT_PIN
+}
+
+template <bool BETA, bool COMPACT>
+__device__ __forceinline__ void sweep(const LatticeArgs& a, const int n, Smem* smem) {
+    const int Tn = a.xn[n], Un = a.yn[n] + 1;
+    const int T = COMPACT ? Tn : a.T, U = COMPACT ? Un : a.U;
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nA = blockDim.x >> 7;                   // compute waves = I/O waves
+    const bool is_io = w >= nA;
+    const int idx = is_io ? w - nA : w;               // column block
+    const size_t nbase = COMPACT ? (size_t)a.offs[n] : (size_t)n * T * U;
+    float* out = (BETA ? a.betas : a.alphas) + nbase;
+    const int ndiag = Tn + Un - 1;
+    const float NEG_INF = -__builtin_inff();
+    Smem& sm = smem[idx];
+
+    const int ucol = WAVE * idx + lane;               // column in sweep coordinates (one pass: Un <= 64*nA)
+    const bool colvalid = ucol < Un;
+    const int u = BETA ? (Un - 1 - ucol) : ucol;
+    const int uc = min(max(u, 0), U - 1);
+    const int ucol_chk = colvalid ? ucol : 0x40000000;
+    const int nwa = min(nA, (Un + WAVE - 1) / WAVE);  // column blocks with a live column
+    const int wave_c = WAVE * idx;
+    const int lo = wave_c / K;
+    const int hi = (min(ndiag, Tn + wave_c + WAVE) + K - 1) / K;
+    const bool live_blk = (idx < nwa) && (lo < hi);
+    // number of global blocks: the last column block finishes computing at hi+idx+1, its I/O wave
+    // stores one block later
+    const int hi_last = (min(ndiag, Tn + WAVE * (nwa - 1) + WAVE) + K - 1) / K;
+    const int G = hi_last + (nwa - 1) + 3 + SHIFT;
+
+    if (!live_blk) {
+        for (int g = 0; g < G; ++g) block_barrier();
+        return;
+    }
+
+    if (is_io) {
+        // ------------------------------ I/O wave ------------------------------
+        const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(out, 0, T * U * 4, RSRC_WORD3);
+        const __amdgpu_buffer_rsrc_t rs_lp = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(a.lp) + nbase * 2, 0, T * U * 8, RSRC_WORD3);
+        const int voff_out = colvalid ? uc * 4 : OOB;
+        const int rowb_lp = U * 8, rowb_out = U * 4;
+        f32x2 regs[NBR][K];
+        // row (forward diagonal mod T) of the next block to LOAD and of the next block to STORE
+        const int dF0 = BETA ? (ndiag - 1 - lo * K) : lo * K;
+        int row_ld = ((dF0 % T) + T) % T;
+        int row_st = row_ld;
+        auto advance = [&](int& row, int (&rows)[K]) {
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                rows[k] = row;
+                row = BETA ? (row == 0 ? T - 1 : row - 1) : (row + 1 == T ? 0 : row + 1);
+            }
+        };
+        auto load_block = [&](f32x2 (&dst)[K]) {
+            int rows[K];
+            advance(row_ld, rows);
+#pragma unroll
+            for (int k = 0; k < K; ++k)
+                dst[k] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rs_lp, uc * 8, rows[k] * rowb_lp, 0));
+        };
+        // local time p: writes pairs(p) to LDS (loaded at p-DLOAD), stores values(p-3), then issues
+        // the loads of pairs(p+DLOAD) -- in that order, so that the youngest loads have a whole block
+        // to land.  GUARDED = near the ends of the live range, where not all three activities exist;
+        // the steady state is straight-line so that the compiler's vmcnt counting is exact.
+        auto io_step = [&](const int p, auto ph, auto guarded) {
+            constexpr int PH = decltype(ph)::value;           // p mod NBR
+            constexpr bool GUARDED = decltype(guarded)::value;
+#ifndef RNNT_WS_NOIO
+            if (!GUARDED || (p >= lo && p < hi)) {
+                f32x2* dst = &sm.pairs[p % PSLOTS][0][lane];
+#pragma unroll
+                for (int k = 0; k < K; ++k) dst[k * WAVE] = regs[PH][k];
+            }
+            const int ps = p - 3;
+            if (!GUARDED || (ps >= lo && ps < hi)) {
+                const float* src = &sm.vals[ps & (VSLOTS - 1)][0][lane];
+                int rows[K];
+                advance(row_st, rows);
+                const int d0 = ps * K;
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    const bool live = (unsigned)(d0 + k - ucol_chk) < (unsigned)Tn;
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, src[k * WAVE]), rs_out,
+                                                          live ? voff_out : OOB, rows[k] * rowb_out, 0);
+                }
+            }
+            if (!GUARDED || (p + DLOAD >= lo && p + DLOAD < hi)) load_block(regs[(PH + DLOAD) % NBR]);
+#endif
+            block_barrier();
+        };
+        auto io_any = [&](const int p, auto guarded) {        // dispatch on p mod NBR
+            const int m = ((p % NBR) + NBR) % NBR;
+            if (m == 0) io_step(p, std::integral_constant<int, 0>{}, guarded);
+            else if (m == 1) io_step(p, std::integral_constant<int, 1>{}, guarded);
+            else io_step(p, std::integral_constant<int, 2>{}, guarded);
+        };
+        // barriers before this wave's first action (global block g = p + idx + SHIFT, first p = lo - DLOAD)
+        const int p_first = lo - DLOAD;
+        int g = 0;
+        for (; g < p_first + idx + SHIFT; ++g) block_barrier();
+        int p = p_first;
+        const int p_end = hi + 3;                          // last store happens at p = hi+2
+        // steady range: all three activities live, p = 0 (mod NBR) at its start
+        int ps0 = lo + 3;
+        ps0 += (NBR - ((ps0 % NBR) + NBR) % NBR) % NBR;
+        const int ps1 = hi - DLOAD;                        // exclusive
+        for (; p < p_end && p < ps0; ++p) io_any(p, std::true_type{});
+        for (; p + NBR <= ps1; p += NBR) {
+            io_step(p, std::integral_constant<int, 0>{}, std::false_type{});
+            io_step(p + 1, std::integral_constant<int, 1>{}, std::false_type{});
+            io_step(p + 2, std::integral_constant<int, 2>{}, std::false_type{});
+        }
+        for (; p < p_end; ++p) io_any(p, std::true_type{});
+        for (g = p + idx + SHIFT; g < G; ++g) block_barrier();
+        static_assert(NBR == 3, "io_step phases are written for a 3-deep register ring");
+        return;
+    }
+
+    // ------------------------------ compute wave ------------------------------
+    float Y = (ucol == 0) ? 0.0f : NEG_INF;
+    float X = NEG_INF;
+    f32x2 bufA[K], bufB[K];
+    auto read_pairs = [&](f32x2 (&dst)[K], const int lb) {
+        const f32x2* src = &sm.pairs[lb % PSLOTS][0][lane];
+#pragma unroll
+        for (int k = 0; k < K; ++k) dst[k] = src[k * WAVE];
+    };
+    auto do_block = [&](const int lb, f32x2 (&cur)[K], f32x2 (&nxt)[K]) {
+        const int d0 = lb * K;
+        float mvec = NEG_INF;
+        if (idx > 0) {
+            if (lane < K) mvec = smem[idx - 1].mail[(d0 - 1 + lane) & (RING - 1)];
+        }
+        if (lb + 1 < hi) read_pairs(nxt, lb + 1);         // written by the I/O wave two blocks ago
+        float* vslot = &sm.vals[lb & (VSLOTS - 1)][0][lane];
+        const bool has_right = idx + 1 < nwa;
+        float* mail_slot = (lane == WAVE - 1) ? &sm.mail[d0 & (RING - 1)] : &sm.trash[lane];
+        const bool full = (d0 >= wave_c + WAVE - 1) && (d0 + K <= wave_c + Tn) && (wave_c + WAVE <= Un);
+        if (full) {
+            if (has_right) compute_block<BETA, false, true>(cur, mvec, Y, X, d0, ucol_chk, Tn, vslot, mail_slot);
+            else compute_block<BETA, false, false>(cur, mvec, Y, X, d0, ucol_chk, Tn, vslot, mail_slot);
+        } else {
+            if (has_right) compute_block<BETA, true, true>(cur, mvec, Y, X, d0, ucol_chk, Tn, vslot, mail_slot);
+            else compute_block<BETA, true, false>(cur, mvec, Y, X, d0, ucol_chk, Tn, vslot, mail_slot);
+        }
+        block_barrier();
+    };
+    int g = 0;
+    for (; g < lo + idx + 2 + SHIFT; ++g) block_barrier();
+    read_pairs(bufA, lo);                                  // first block: exposed LDS latency once
+    int lb = lo;
+    for (; lb + 2 <= hi; lb += 2) {
+        do_block(lb, bufA, bufB);
+        do_block(lb + 1, bufB, bufA);
+    }
+    if (lb < hi) { do_block(lb, bufA, bufB); ++lb; }
+    for (g = lb + idx + 2 + SHIFT; g < G; ++g) block_barrier();
+    if constexpr (!BETA) {
+        // Y of a finished lane is frozen at alpha + lpB of its last live cell (core_gather.cu:339)
+        if (ucol == Un - 1) a.ll[n] = Y;
+    }
+}
+
+template <bool COMPACT>
+__global__ void __launch_bounds__(2 * MAXA * WAVE) k_lattice_ws(const LatticeArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    Smem* smem = reinterpret_cast<Smem*>(smem_raw);
+    const int n = blockIdx.x >> 1;
+    if (blockIdx.x & 1)
+        sweep<true, COMPACT>(a, n, smem);
+    else
+        sweep<false, COMPACT>(a, n, smem);
+}
+
+}  // namespace ws
+
+// Returns hipErrorNotSupported when the lattice is too wide for one pass (caller falls back to
+// the single-role kernel of lattice.hip).
+hipError_t launch_lattice_ws(hipStream_t stream, const LatticeArgs& a, int N) {
+    if (N <= 0) return hipSuccess;
+    const int nA = (a.U + WAVE - 1) / WAVE;
+    if (nA > ws::MAXA) return hipErrorNotSupported;
+    const size_t lds = sizeof(ws::Smem) * nA;
+    const dim3 grid(2 * N), block(2 * nA * WAVE);
+    static bool attr_set[2] = {false, false};
+    const int ci = a.offs ? 1 : 0;
+    if (!attr_set[ci]) {
+        const void* fn = a.offs ? reinterpret_cast<const void*>(&ws::k_lattice_ws<true>)
+                                : reinterpret_cast<const void*>(&ws::k_lattice_ws<false>);
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)(sizeof(ws::Smem) * ws::MAXA));
+        if (e != hipSuccess) return e;
+        attr_set[ci] = true;
+    }
+    if (a.offs)
+        ws::k_lattice_ws<true><<<grid, block, lds, stream>>>(a);
+    else
+        ws::k_lattice_ws<false><<<grid, block, lds, stream>>>(a);
+    return hipGetLastError();
+}
+
+}  // namespace rnnt
