@@ -245,6 +245,9 @@ __device__ __forceinline__ void sweep(const LatticeArgs& a, const int n, Smem* s
     }
 
     // ------------------------------ compute wave ------------------------------
+#ifdef RNNT_WS_PRIO
+    __builtin_amdgcn_s_setprio(3);   // the dependent chain is the critical path; I/O waves yield
+#endif
     float Y = (ucol == 0) ? 0.0f : NEG_INF;
     float X = NEG_INF;
     f32x2 bufA[K], bufB[K];
