@@ -27,3 +27,16 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if "gpu" in item.keywords:
             item.add_marker(skip)
+
+
+def pytest_sessionstart(session):
+    """Build the native pieces once per session if they are missing or stale (hipcc and gcc are in
+    the image on both the build container and the GPU box).  The product itself never builds
+    implicitly: a missing library is a loud error there."""
+    try:
+        from warp_rnnt_amd import _build
+        _build.build()
+        import oracle
+        oracle.build()
+    except Exception as e:   # let the individual tests report the problem
+        print("native build failed in conftest:", e)
