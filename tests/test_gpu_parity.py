@@ -281,3 +281,24 @@ def test_config4_size_invariants_and_fp64():
           f"{np.abs(g - ref['grads']).max():.3e}")
     assert err_hip < 3e-2                      # fp32-vs-exact at this size (~1e-2)
     assert err_hip < 3.0 * err_ora + 1e-3      # no worse than the reference-ordered fp32 restatement
+
+
+# ----------------------------------------------------------------------------
+# 7. shape fuzz around the kernels' structural boundaries (column blocks of 64, the 512-column
+#    limit of the wave-specialised lattice kernel, blocks of 8 diagonals, 32x32 gather tiles)
+# ----------------------------------------------------------------------------
+FUZZ = [(3, t, u) for u in (1, 2, 31, 32, 33, 63, 64, 65, 127, 128, 129) for t in (1, 2, 7, 8, 9, 33)] + \
+       [(2, 20, 511), (2, 20, 512), (2, 20, 513), (1, 70, 600), (2, 257, 300), (2, 5, 1025)]
+
+
+def test_shape_fuzz_vs_oracle():
+    rng = np.random.RandomState(99)
+    for i, (N, T, U) in enumerate(FUZZ):
+        V = int(rng.choice([2, 3, 5, 9])) if U > 1 else 3
+        logits, labels, xn, yn = make_case(1000 + i, N, T, U, V, ragged=bool(i % 2))
+        lp = np_log_softmax32(logits)
+        lam = 0.0 if i % 3 else 0.03
+        ref = oracle.rnnt_loss_f32(lp, labels, xn, yn, blank=0, fastemit_lambda=lam, scan_mode=1)
+        c, g = run_native(lp, labels, xn, yn, blank=0, lam=lam)
+        np.testing.assert_allclose(c, ref["costs"], rtol=COST_RTOL, err_msg=f"case {N},{T},{U},{V}")
+        np.testing.assert_allclose(g, ref["grads"], atol=GRAD_ATOL, err_msg=f"case {N},{T},{U},{V}")

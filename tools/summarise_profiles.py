@@ -1,0 +1,65 @@
+#!/usr/bin/env python
+"""gpurun_out/r01/* (written by tools/collect_profiles.sh) -> small committed summaries under profiles/."""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "gpurun_out", "r01")
+DST = os.path.join(ROOT, "profiles")
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r01"
+
+
+def pmc_summary(dirs, out):
+    agg = collections.defaultdict(list)
+    for d in dirs:
+        for f in glob.glob(os.path.join(SRC, d, "*_counter_collection.csv")):
+            for r in csv.DictReader(open(f)):
+                if "rnnt::" in r["Kernel_Name"]:
+                    k = r["Kernel_Name"].split("(")[0].replace("void ", "")
+                    agg[(k, r["Counter_Name"])].append(float(r["Counter_Value"]))
+    with open(out, "w", newline="") as fh:
+        w = csv.writer(fh)
+        w.writerow(["kernel", "counter", "dispatches", "mean_per_dispatch"])
+        for (k, c), v in sorted(agg.items()):
+            w.writerow([k, c, len(v), round(sum(v) / len(v), 1)])
+    return agg
+
+
+def main():
+    os.makedirs(DST, exist_ok=True)
+    for c in ("c2", "c3", "c4", "c5"):
+        src = os.path.join(SRC, f"bench_{c}.json")
+        if os.path.exists(src) and os.path.getsize(src):
+            shutil.copy(src, os.path.join(DST, f"{TAG}_bench_{c}.json"))
+    for c in ("c2", "c3", "c4"):
+        db = os.path.join(SRC, f"stats_{c}", f"{c}_results.db")
+        if os.path.exists(db):
+            subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "rocprof_summary.py"), db,
+                                   os.path.join(DST, f"{TAG}_rocprof_{c}_kernel_stats.csv")])
+    agg = pmc_summary(["pmc_fetch", "pmc_write"], os.path.join(DST, f"{TAG}_rocprof_c4_pmc_hbm.csv"))
+    pmc_summary(["pmc_sq1", "pmc_sq2"], os.path.join(DST, f"{TAG}_rocprof_c4_pmc_sq.csv"))
+    for f in glob.glob(os.path.join(SRC, "table_*.md")):
+        shutil.copy(f, os.path.join(DST, f"{TAG}_" + os.path.basename(f)))
+    # HBM traffic of the dominant kernel, per launch (FETCH_SIZE doubled for wide coalesced reads)
+    key_f = [k for k in agg if "k_lsm_small" in k[0] and "0>" in k[0].replace(" ", "") and k[1] == "FETCH_SIZE"]
+    key_w = [k for k in agg if "k_lsm_small" in k[0] and "0>" in k[0].replace(" ", "") and k[1] == "WRITE_SIZE"]
+    if key_f and key_w:
+        f_kib = sum(agg[key_f[0]]) / len(agg[key_f[0]])
+        w_kib = sum(agg[key_w[0]]) / len(agg[key_w[0]])
+        json.dump({"_about": "HBM bytes per launch of the log-softmax kernel from rocprofv3 --pmc FETCH_SIZE / "
+                             "WRITE_SIZE (separate passes, profiles/%s_rocprof_c4_pmc_hbm.csv); FETCH_SIZE doubled for "
+                             "wide coalesced reads as MI355X_MICROARCH.md (HBM) prescribes" % TAG,
+                   "c4": {"kernel": key_f[0][0], "fetch_size_kib": f_kib, "write_size_kib": w_kib,
+                          "traffic_bytes": f_kib * 2048 + w_kib * 1024}},
+                  open(os.path.join(DST, "hbm_traffic.json"), "w"), indent=1)
+    print(sorted(os.listdir(DST)))
+
+
+if __name__ == "__main__":
+    main()

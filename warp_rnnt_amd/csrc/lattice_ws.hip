@@ -313,15 +313,18 @@ hipError_t launch_lattice_ws(hipStream_t stream, const LatticeArgs& a, int N) {
     if (nA > ws::MAXA) return hipErrorNotSupported;
     const size_t lds = sizeof(ws::Smem) * nA;
     const dim3 grid(2 * N), block(2 * nA * WAVE);
-    static bool attr_set[2] = {false, false};
+    // > 64 KiB of dynamic LDS needs an opt-in per kernel and per device (one-time, idempotent)
+    static bool attr_set[2][64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
     const int ci = a.offs ? 1 : 0;
-    if (!attr_set[ci]) {
+    if (!attr_set[ci][dev]) {
         const void* fn = a.offs ? reinterpret_cast<const void*>(&ws::k_lattice_ws<true>)
                                 : reinterpret_cast<const void*>(&ws::k_lattice_ws<false>);
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize,
                                            (int)(sizeof(ws::Smem) * ws::MAXA));
         if (e != hipSuccess) return e;
-        attr_set[ci] = true;
+        attr_set[ci][dev] = true;
     }
     if (a.offs)
         ws::k_lattice_ws<true><<<grid, block, lds, stream>>>(a);
