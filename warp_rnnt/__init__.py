@@ -1,10 +1,12 @@
-"""Drop-in replacement for the ``warp_rnnt`` package of 1ytic/warp-rnnt on AMD MI355X.
+"""Drop-in ``warp_rnnt`` package for AMD MI355X.
 
-Mirrors pytorch_binding/warp_rnnt/__init__.py:9-24,57-143: ``rnnt_loss`` keeps the signature,
-the assert/exception behaviour, ``average_frames`` / ``reduction`` semantics and the autograd
-contract (gradients w.r.t. ``log_probs`` are computed in the forward pass, ``backward`` scales them by
-the incoming per-utterance gradient).  Everything numeric runs in hand-written HIP kernels
-(warp_rnnt_amd/csrc); see DESIGN.md.
+Public surface = the reference's (pytorch_binding/warp_rnnt/__init__.py:9-24 ``RNNTLoss``,
+:26-54 ``RNNTLossCompact``, :57-143 ``rnnt_loss``): same call signatures, same flag checking
+(``AssertionError`` for ill-typed flags or differentiable integer inputs, ``ValueError`` text for
+an unknown reduction), same ``average_frames`` / ``reduction`` arithmetic, and the same autograd
+contract -- the gradient w.r.t. ``log_probs`` is produced during the forward pass and ``backward``
+only scales it by the incoming per-utterance gradient.  All numerics run in the hand-written HIP
+kernels of ``warp_rnnt_amd/csrc``; there is no CPU path.
 """
 from typing import Optional
 
@@ -14,80 +16,96 @@ from . import _C as core
 
 __version__ = "0.7.0+amd.mi355x"
 
+_REDUCTIONS = ("none", "mean", "sum")
+
+
+def _per_utterance(t, like):
+    """(N,) upstream gradient broadcastable against a per-cell gradient tensor."""
+    return t.reshape(-1, *([1] * (like.dim() - 1))).to(like)
+
 
 class RNNTLoss(torch.autograd.Function):
-    """log_probs in the layout the native op takes (dense, or gathered with blank=-1)."""
+    """Loss on ``log_probs`` in the layout the native op takes: dense ``(N,T,U,V)``, or the
+    2-channel (blank, label) layout when ``blank == -1``.  Six inputs, six gradients
+    (the reference returns a seventh, spurious ``None``)."""
 
     @staticmethod
     def forward(ctx, log_probs, labels, frames_lengths, labels_lengths, blank=0, fastemit_lambda=0.0):
-        costs, grads = core.rnnt_loss(
-            xs=log_probs, ys=labels,
-            xn=frames_lengths, yn=labels_lengths,
-            blank=blank,
-            fastemit_lambda=fastemit_lambda,
-        )
-        ctx.grads = grads
+        costs, ctx.grads = core.rnnt_loss(xs=log_probs, ys=labels, xn=frames_lengths, yn=labels_lengths,
+                                          blank=blank, fastemit_lambda=fastemit_lambda)
         return costs
 
     @staticmethod
     def backward(ctx, grads_output):
-        grads_output = grads_output.view(-1, 1, 1, 1).to(ctx.grads)
-        return ctx.grads * grads_output, None, None, None, None, None
+        # out of place: a second backward (retain_graph) sees the same gradient again
+        return (ctx.grads * _per_utterance(grads_output, ctx.grads),) + (None,) * 5
 
 
 class RNNTLossGather(torch.autograd.Function):
-    """``gather=True``: dense log_probs in; the gather prologue, the loss and the scatter
-    backward are native kernels (no int64 index tensor, no dense zero-fill + scatter_add)."""
+    """``gather=True``.  The reference builds an int64 index, calls ``torch.gather`` and lets autograd
+    scatter-add the result back into a dense zero tensor (__init__.py:118-128); here the gather, the
+    loss and the dense expansion of the gradient are three native kernels and no index exists."""
 
     @staticmethod
     def forward(ctx, log_probs, labels, frames_lengths, labels_lengths, blank=0, fastemit_lambda=0.0):
-        costs, grads = core.rnnt_loss_gather(
-            xs=log_probs, ys=labels,
-            xn=frames_lengths, yn=labels_lengths,
-            blank=blank,
-            fastemit_lambda=fastemit_lambda,
-        )
-        ctx.grads = grads
-        ctx.aux = (labels, frames_lengths, labels_lengths, log_probs.size(3), blank)
+        costs, pairs_grad = core.rnnt_loss_gather(xs=log_probs, ys=labels, xn=frames_lengths,
+                                                  yn=labels_lengths, blank=blank,
+                                                  fastemit_lambda=fastemit_lambda)
+        ctx.pairs_grad = pairs_grad
+        ctx.meta = (labels, frames_lengths, labels_lengths, log_probs.size(3), blank)
         return costs
 
     @staticmethod
     def backward(ctx, grads_output):
-        labels, xn, yn, V, blank = ctx.aux
-        go = grads_output.reshape(-1).to(ctx.grads).contiguous()
-        dense = core.rnnt_loss_gather_backward(go, ctx.grads, labels, xn, yn, V, blank)
-        return dense, None, None, None, None, None
+        labels, xn, yn, vocab, blank = ctx.meta
+        scale = grads_output.reshape(-1).to(ctx.pairs_grad).contiguous()
+        dense = core.rnnt_loss_gather_backward(scale, ctx.pairs_grad, labels, xn, yn, vocab, blank)
+        return (dense,) + (None,) * 5
 
 
 class RNNTLossCompact(torch.autograd.Function):
-    """Compact (ragged packed) layout, mirror of __init__.py:26-54."""
+    """Ragged packed layout: ``log_probs`` is ``(sum_n T_n*(U_n+1), V)``, ``labels`` is ``(sum_n U_n,)``."""
 
     @staticmethod
     def forward(ctx, log_probs, labels, frames_lengths, labels_lengths, blank=0, fastemit_lambda=0.0,
                 enable_grad: bool = True):
-        costs, grads, loc = core.rnnt_loss_compact(
-            xs=log_probs, ys=labels,
-            xn=frames_lengths, yn=labels_lengths,
-            blank=blank,
-            fastemit_lambda=fastemit_lambda,
-            required_grad=enable_grad
-        )
+        costs, pairs_grad, loc = core.rnnt_loss_compact(xs=log_probs, ys=labels, xn=frames_lengths,
+                                                        yn=labels_lengths, blank=blank,
+                                                        fastemit_lambda=fastemit_lambda,
+                                                        required_grad=enable_grad)
         if enable_grad:
-            cumlen = torch.cumsum(frames_lengths * (labels_lengths + 1), dim=0, dtype=torch.int32)
-            ctx.V = log_probs.size(-1)
-            ctx.blank = blank
-            ctx.save_for_backward(grads, loc, cumlen)
+            rows_per_utt = frames_lengths * (labels_lengths + 1)
+            ctx.save_for_backward(pairs_grad, loc, torch.cumsum(rows_per_utt, dim=0, dtype=torch.int32))
+            ctx.vocab, ctx.blank = log_probs.size(-1), blank
         return costs
 
     @staticmethod
     def backward(ctx, grads_output):
-        grads, loc, cumlen = ctx.saved_tensors
-        grads_input = core.rnnt_loss_compact_backward(
-            grads_output.contiguous(),
-            grads, cumlen,
-            loc, ctx.V, ctx.blank
-        )
-        return grads_input, None, None, None, None, None, None
+        pairs_grad, loc, row_ends = ctx.saved_tensors
+        dense = core.rnnt_loss_compact_backward(grads_output.contiguous(), pairs_grad, row_ends, loc,
+                                                ctx.vocab, ctx.blank)
+        return (dense,) + (None,) * 6
+
+
+def _check_call(average_frames, reduction, blank, gather, labels, frames_lengths, labels_lengths):
+    # the reference uses bare asserts (__init__.py:100-107); keep the exception type
+    assert isinstance(average_frames, bool) or average_frames is None, "average_frames must be a bool"
+    assert reduction in _REDUCTIONS or reduction is None, "reduction must be one of %s" % (_REDUCTIONS,)
+    assert isinstance(blank, int), "blank must be an int"
+    assert isinstance(gather, bool), "gather must be a bool"
+    for t, what in ((labels, "labels"), (frames_lengths, "frames_lengths"), (labels_lengths, "labels_lengths")):
+        assert not t.requires_grad, what + " does not require gradients"
+
+
+def _reduce(costs, reduction):
+    if reduction in (None, "none"):
+        return costs
+    if reduction == "sum":
+        return costs.sum()
+    if reduction == "mean":
+        return costs.mean()
+    raise ValueError(
+        f"Unknown reduction method: {reduction}, expected to be one of ['mean', 'sum', 'none']")
 
 
 def rnnt_loss(log_probs: torch.FloatTensor,
@@ -100,52 +118,31 @@ def rnnt_loss(log_probs: torch.FloatTensor,
               gather: bool = False,
               fastemit_lambda: float = 0.0,
               compact: bool = False) -> torch.Tensor:
-    """RNN-Transducer loss (same arguments as the reference, __init__.py:57-98).
+    """RNN-Transducer negative log-likelihood of a minibatch.
 
-    Args:
-        log_probs: (N, T, U, V) log-probabilities (already log-softmaxed), fp32, contiguous, on GPU.
-        labels: (N, U-1) int32 reference labels.
-        frames_lengths: (N,) int32 number of frames per utterance.
-        labels_lengths: (N,) int32 number of labels per utterance.
-        average_frames: divide each utterance's loss by its number of frames.
-        reduction: 'none' | 'mean' | 'sum' (None = 'none').
-        blank: index of the blank symbol.
-        gather: run the lattice on the 2-channel (blank, label) view of ``log_probs``.
-        fastemit_lambda: FastEmit regularisation weight (https://arxiv.org/abs/2010.11148).
-        compact: ragged packed layout: log_probs (STU, V) with STU = sum(frames_lengths*(labels_lengths+1)),
-            labels (sum(labels_lengths),).
+    ``log_probs``       fp32, contiguous, on the GPU, already log-softmaxed over the last axis:
+                        ``(N, T, U, V)`` (T frames, U = longest label sequence + 1, V symbols incl. blank)
+                        or, with ``compact=True``, the ragged ``(sum_n T_n*(U_n+1), V)`` packing.
+    ``labels``          int32 ``(N, U-1)`` (``(sum_n U_n,)`` when compact).
+    ``frames_lengths``  int32 ``(N,)`` -- T_n.
+    ``labels_lengths``  int32 ``(N,)`` -- U_n.
+    ``average_frames``  divide every utterance's cost by T_n before the reduction.
+    ``reduction``       ``'none'`` / ``None`` -> ``(N,)`` costs, ``'sum'``, ``'mean'``.
+    ``blank``           vocabulary index of the blank symbol.
+    ``gather``          run on the 2-channel (blank, label) view of ``log_probs``; same result, the
+                        gradient tensor kept for backward is ``V/2`` times smaller.
+    ``fastemit_lambda`` FastEmit weight (arXiv:2010.11148): scales the label gradients by ``1+lambda``.
     """
-    assert average_frames is None or isinstance(average_frames, bool)
-    assert reduction is None or reduction in ("none", "mean", "sum")
-    assert isinstance(blank, int)
-    assert isinstance(gather, bool)
-
-    assert not labels.requires_grad, "labels does not require gradients"
-    assert not frames_lengths.requires_grad, "frames_lengths does not require gradients"
-    assert not labels_lengths.requires_grad, "labels_lengths does not require gradients"
+    _check_call(average_frames, reduction, blank, gather, labels, frames_lengths, labels_lengths)
 
     if compact:
-        costs = RNNTLossCompact.apply(
-            log_probs.float(),
-            labels, frames_lengths,
-            labels_lengths, blank,
-            fastemit_lambda,
-            (log_probs.requires_grad and torch.is_grad_enabled())
-        )
-    elif gather:
-        costs = RNNTLossGather.apply(log_probs, labels, frames_lengths, labels_lengths, blank, fastemit_lambda)
+        wants_grad = log_probs.requires_grad and torch.is_grad_enabled()
+        costs = RNNTLossCompact.apply(log_probs.float(), labels, frames_lengths, labels_lengths, blank,
+                                      fastemit_lambda, wants_grad)
     else:
-        costs = RNNTLoss.apply(log_probs, labels, frames_lengths, labels_lengths, blank, fastemit_lambda)
+        fn = RNNTLossGather if gather else RNNTLoss
+        costs = fn.apply(log_probs, labels, frames_lengths, labels_lengths, blank, fastemit_lambda)
 
     if average_frames:
         costs = costs / frames_lengths.to(log_probs)
-
-    if reduction == "none" or reduction is None:
-        return costs
-    elif reduction == "sum":
-        return costs.sum()
-    elif reduction == "mean":
-        return costs.mean()
-    else:
-        raise ValueError(
-            f"Unknown reduction method: {reduction}, expected to be one of ['mean', 'sum', 'none']")
+    return _reduce(costs, reduction)
