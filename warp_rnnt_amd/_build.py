@@ -35,7 +35,8 @@ def build(force=False, verbose=False, extra_flags=()):
     objdir = os.path.join(HERE, "build")
     os.makedirs(objdir, exist_ok=True)
     hdrs = [os.path.normpath(os.path.join(CSRC, h)) for h in HEADERS]
-    flags = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+    flags = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
+             "-fno-slp-vectorize"]   # the lattice chains must stay scalar (v_pk_add_f32 costs two issue slots)
     flags += list(extra_flags)
 
     def compile_one(src):

@@ -67,47 +67,75 @@ __device__ __forceinline__ void compute_block(const f32x2 (&cur)[K], const float
 #pragma unroll
     for (int k = 0; k < K; ++k) first[k] = readlane(mvec, k);
 #define RNNT_PIN() __builtin_amdgcn_sched_barrier(0)
-    // The LDS writes of step k (value, hand-over) are issued right AFTER the DPP of step k+1, in
-    // its latency shadow, instead of between the value and the DPP that depends on it.
-    float pval = 0.0f, pX = 0.0f;
+    // A lone wave issues one instruction per ~5.8 cycles whatever it is (tools/ubench/step_order.hip),
+    // so the step is ordered to need NO hazard nops: the LDS write and the next skip/Y add sit between
+    // the value and the DPP that reads it (2 wait states), v_max sits behind v_exp_f32 (1 wait state),
+    // and the v_mov that seeds the next DPP's lane 0 is issued well before it.
+    float fk = first[0];
+    asm volatile("" : "+v"(fk));   // materialise the DPP's lane-0 seed in a VGPR here, not next to the DPP
+    RNNT_PIN();
+    float pval = 0.0f;
 #pragma unroll
     for (int k = 0; k < K; ++k) {
-        const float left = wave_shr1(first[k], X);                                     // chain
-        RNNT_PIN();
-        if (k > 0) {
-#ifndef RNNT_WS_NOVAL
-            vslot[(k - 1) * WAVE] = pval;
-#endif
-            if constexpr (MAIL) mail_slot[k - 1] = pX;
-            RNNT_PIN();
-        }
         float skip, emit;
-        if constexpr (BETA) { skip = Y + cur[k].x; emit = left + cur[k].y; }           // chain
-        else { skip = Y; emit = left; }
+        if constexpr (BETA) {
+            // beta: the value of the previous diagonal is published, then extended by this cell's
+            // blank log-prob -- both read `Y` and sit between its producer and the DPP below
+            if (k > 0) {
+#ifndef RNNT_WS_NOVAL
+                vslot[(k - 1) * WAVE] = pval;
+#endif
+                RNNT_PIN();
+            }
+            skip = Y + cur[k].x;
+            RNNT_PIN();
+        } else {
+            skip = Y;
+        }
+        const float left = wave_shr1(fk, X);                                           // chain
+        RNNT_PIN();
+        if constexpr (BETA) {
+            emit = left + cur[k].y;                                                    // chain (scalar add: the
+                                                                                       // file is built with -fno-slp-vectorize)
+        } else {
+            emit = left;
+        }
         RNNT_PIN();
         // lse(skip, emit) = max + log1p(exp(-|skip-emit|)), see lattice.hip
         const float t = skip - emit;                                                   // chain
-        RNNT_PIN();
-        float mx;
-        asm("v_max_f32 %0, %1, %2" : "=v"(mx) : "v"(skip), "v"(emit));                 // shadow
         RNNT_PIN();
         const float m = -__builtin_fabsf(t) * 1.44269504088896340736f;                 // chain
         RNNT_PIN();
         const float e = __builtin_amdgcn_exp2f(m);                                     // chain
         RNNT_PIN();
+        const float mx = __builtin_fmaxf(skip, emit);                                  // fills the trans wait state
+        RNNT_PIN();
         const float u = 1.0f + e;                                                      // chain
         RNNT_PIN();
         const float l2 = __builtin_amdgcn_logf(u);                                     // chain
         RNNT_PIN();
-        const float c = e - (u - 1.0f);                                                // shadow
+        if (k + 1 < K) { fk = first[k + 1]; asm volatile("" : "+v"(fk)); RNNT_PIN(); }
+        const float um1 = u - 1.0f;
+        RNNT_PIN();
+        const float c = e - um1;
         RNNT_PIN();
         const float l = __builtin_fmaf(l2, 0.693147180559945309417f, c);               // chain
         RNNT_PIN();
         const float val = mx + l;                                                      // chain
         RNNT_PIN();
         float Yn, Xn;
-        if constexpr (BETA) { Yn = val; Xn = val; }
-        else { Xn = val + cur[k].y; RNNT_PIN(); Yn = val + cur[k].x; }
+        if constexpr (BETA) {
+            Yn = val; Xn = val;
+        } else {
+            Xn = val + cur[k].y;                                                       // chain (feeds the DPP)
+            RNNT_PIN();
+#ifndef RNNT_WS_NOVAL
+            vslot[k * WAVE] = val;
+#endif
+            RNNT_PIN();
+            Yn = val + cur[k].x;
+            RNNT_PIN();
+        }
         if constexpr (MASKED) {
             const bool live = (unsigned)(d0 + k - ucol_chk) < (unsigned)Tn;
             Y = live ? Yn : Y;
@@ -115,13 +143,14 @@ __device__ __forceinline__ void compute_block(const f32x2 (&cur)[K], const float
         } else {
             Y = Yn; X = Xn;
         }
-        pval = val; pX = X;
-        RNNT_PIN();
+        pval = val;
+        if constexpr (MAIL) { mail_slot[k] = X; RNNT_PIN(); }
     }
+    if constexpr (BETA) {
 #ifndef RNNT_WS_NOVAL
-    vslot[(K - 1) * WAVE] = pval;
+        vslot[(K - 1) * WAVE] = pval;
 #endif
-    if constexpr (MAIL) mail_slot[K - 1] = pX;
+    }
 #undef RNNT_PIN
 }
 
