@@ -11,74 +11,127 @@
 // Either way the reference pays a full zero-fill pass plus scattered 4-byte
 // writes; here every output row is produced once, zeros included, with
 // 16-byte coalesced stores, and the int64 index tensor never exists.
+//
+// The kernels are pure HBM writers (4V+8 bytes per cell), so the work per
+// element is kept to a fraction of an instruction: small vocabularies build a
+// tile of whole rows in LDS (zero fill with ds_write_b128, two 4-byte patches
+// per cell by one lane, ds_read_b128 + 16-byte stores out); large vocabularies
+// write zeros straight from registers and compare the column index against the
+// cell's two slots.  (The first version -- one thread per float4 with its own
+// index divisions -- was VALU-bound at 2.4 TB/s.)
 #include "common.h"
 #include "kernels.h"
 
 namespace rnnt {
 
+struct ExpandCell {
+    float gB, gL;   // scaled gradients of the blank and label slot
+    int lab;        // vocabulary index of the label slot, or -1 when nothing goes there
+};
+
+// cell = flat (n,t,u) index.  N*T*U < 2^32 is checked by the C ABI.
+__device__ __forceinline__ ExpandCell expand_cell(unsigned cell, const float2* __restrict__ g2,
+                                                  const int* __restrict__ labels, const int* __restrict__ xn,
+                                                  const int* __restrict__ yn, const float* __restrict__ scale,
+                                                  int T, int U, int blank, int overwrite) {
+    const unsigned frame = cell / (unsigned)U;
+    const int u = (int)(cell - frame * (unsigned)U);
+    const unsigned n = frame / (unsigned)T;
+    const int t = (int)(frame - n * (unsigned)T);
+    int r = t + u;
+    r = r >= T ? r % T : r;
+    const float sc = scale ? scale[n] : 1.0f;
+    const float2 g = g2[((size_t)n * T + r) * (size_t)U + u];
+    ExpandCell c;
+    c.gB = g.x * sc;
+    c.gL = g.y * sc;
+    c.lab = (u < U - 1) ? labels[(size_t)n * (U - 1) + u] : blank;
+    if (overwrite) {
+        // dense-kernel rule (core.cu:382-393): the label slot is written only for live cells with a
+        // label, after the blank slot
+        const bool labvalid = (t < xn[n]) && (u < yn[n]);
+        if (!labvalid) c.lab = -1;
+        else if (c.lab == blank) c.gB = c.gL;      // label write lands on the blank slot and wins
+        if (labvalid && c.lab == blank) c.lab = -1;
+    }
+    return c;
+}
+
+// ---- V <= 1024: R whole rows per workgroup through LDS ----
+constexpr int EX_THREADS = 256;
+constexpr int EX_FLOATS = 3200;
+
+__global__ void __launch_bounds__(EX_THREADS)
+k_expand_small(const float2* __restrict__ g2, const int* __restrict__ labels, const int* __restrict__ xn,
+               const int* __restrict__ yn, const float* __restrict__ scale, float* __restrict__ dense,
+               unsigned cells, int R, int T, int U, int V, int blank, int overwrite) {
+    extern __shared__ __attribute__((aligned(16))) float tile[];
+    const int tid = threadIdx.x;
+    const unsigned cell0 = blockIdx.x * (unsigned)R;
+    const int nrows = (int)min((unsigned)R, cells - cell0);
+    const int nel = nrows * V;
+    const int nvec = nel >> 2;
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i = tid; i < nvec; i += EX_THREADS) reinterpret_cast<float4*>(tile)[i] = z;
+    for (int e = (nvec << 2) + tid; e < nel; e += EX_THREADS) tile[e] = 0.f;
+    __syncthreads();
+    for (int r = tid; r < nrows; r += EX_THREADS) {
+        const ExpandCell c = expand_cell(cell0 + r, g2, labels, xn, yn, scale, T, U, blank, overwrite);
+        float* row = tile + r * V;
+        row[blank] = c.gB;
+        if (c.lab >= 0) row[c.lab] += c.gL;     // scatter-add semantics when label == blank (sum mode)
+    }
+    __syncthreads();
+    float* dst = dense + (size_t)cell0 * V;
+    for (int i = tid; i < nvec; i += EX_THREADS)
+        reinterpret_cast<float4*>(dst)[i] = reinterpret_cast<const float4*>(tile)[i];
+    for (int e = (nvec << 2) + tid; e < nel; e += EX_THREADS) dst[e] = tile[e];
+}
+
+// ---- larger V: one row per workgroup iteration, zeros from registers ----
 template <int VEC>
 __global__ void __launch_bounds__(256)
-k_expand(const float2* __restrict__ g2, const int* __restrict__ labels, const int* __restrict__ xn,
-         const int* __restrict__ yn, const float* __restrict__ scale, float* __restrict__ dense,
-         int T, int U, int V, int blank, int overwrite) {
-    const size_t frame = blockIdx.x;                 // n*T + t
-    const unsigned UV = (unsigned)U * (unsigned)V;
-    const unsigned e0 = (blockIdx.y * 256u + threadIdx.x) * VEC;
-    if (e0 >= UV) return;
-    const size_t n = frame / (unsigned)T;
-    const int t = (int)(frame - n * (unsigned)T);
-    const float sc = scale ? scale[n] : 1.0f;
-    const int Tn = xn[n], Un = yn[n] + 1;
-
-    int u = e0 / (unsigned)V;
-    int v = e0 - u * V;
-    float out[VEC];
-    int cu = -1;
-    float gB = 0.f, gL = 0.f;
-    int lab = -1;
-    bool labvalid = false;
+k_expand_large(const float2* __restrict__ g2, const int* __restrict__ labels, const int* __restrict__ xn,
+               const int* __restrict__ yn, const float* __restrict__ scale, float* __restrict__ dense,
+               unsigned cells, int T, int U, int V, int blank, int overwrite) {
+    for (unsigned cell = blockIdx.x; cell < cells; cell += gridDim.x) {
+        const ExpandCell c = expand_cell(cell, g2, labels, xn, yn, scale, T, U, blank, overwrite);
+        float* dst = dense + (size_t)cell * V;
+        for (int v0 = threadIdx.x * VEC; v0 < V; v0 += 256 * VEC) {
+            float o[VEC];
 #pragma unroll
-    for (int j = 0; j < VEC; ++j) {
-        if (u != cu && u < U) {
-            cu = u;
-            int r = t + u;
-            r = r >= T ? r % T : r;
-            const float2 g = g2[(n * T + r) * (size_t)U + u];
-            gB = g.x * sc; gL = g.y * sc;
-            lab = (u < U - 1) ? labels[n * (size_t)(U - 1) + u] : blank;
-            labvalid = (t < Tn) && (u < Un - 1);
+            for (int j = 0; j < VEC; ++j) {
+                const int v = v0 + j;
+                o[j] = ((v == blank) ? c.gB : 0.0f) + ((v == c.lab) ? c.gL : 0.0f);
+            }
+            if constexpr (VEC == 4) *reinterpret_cast<float4*>(dst + v0) = make_float4(o[0], o[1], o[2], o[3]);
+            else dst[v0] = o[0];
         }
-        float val;
-        if (overwrite)
-            val = (v == lab && labvalid) ? gL : (v == blank ? gB : 0.0f);
-        else
-            val = (v == blank ? gB : 0.0f) + (v == lab ? gL : 0.0f);
-        out[j] = val;
-        if (++v == V) { v = 0; ++u; }
-    }
-    float* dst = dense + frame * (size_t)UV + e0;
-    if constexpr (VEC == 4) {
-        *reinterpret_cast<float4*>(dst) = make_float4(out[0], out[1], out[2], out[3]);
-    } else {
-        dst[0] = out[0];
     }
 }
 
 hipError_t launch_expand(hipStream_t stream, const float* g2_skewed, const int* labels, const int* xn,
                          const int* yn, const float* scale, float* dense, int N, int T, int U, int V,
                          int blank, int overwrite_mode) {
-    const size_t frames = (size_t)N * T;
-    if (frames == 0 || U == 0 || V == 0) return hipSuccess;
-    const unsigned UV = (unsigned)U * (unsigned)V;
-    const bool vec = (UV % 4 == 0) && (reinterpret_cast<uintptr_t>(dense) % 16 == 0);
-    if (vec) {
-        const dim3 grid((unsigned)frames, (UV / 4 + 255) / 256);
-        k_expand<4><<<grid, 256, 0, stream>>>(reinterpret_cast<const float2*>(g2_skewed), labels, xn, yn,
-                                              scale, dense, T, U, V, blank, overwrite_mode);
+    const size_t cells64 = (size_t)N * T * U;
+    if (cells64 == 0 || V == 0) return hipSuccess;
+    const unsigned cells = (unsigned)cells64;
+    const float2* g2 = reinterpret_cast<const float2*>(g2_skewed);
+    const bool aligned = reinterpret_cast<uintptr_t>(dense) % 16 == 0;
+    if (aligned && V <= 1024) {
+        int R = (EX_FLOATS / V) / 4 * 4;          // R % 4 == 0 keeps every tile start 16-byte aligned
+        if (R < 4) R = 4;
+        const size_t lds = (size_t)R * V * sizeof(float);
+        k_expand_small<<<(cells + R - 1) / R, EX_THREADS, lds, stream>>>(g2, labels, xn, yn, scale, dense, cells,
+                                                                          R, T, U, V, blank, overwrite_mode);
     } else {
-        const dim3 grid((unsigned)frames, (UV + 255) / 256);
-        k_expand<1><<<grid, 256, 0, stream>>>(reinterpret_cast<const float2*>(g2_skewed), labels, xn, yn,
-                                              scale, dense, T, U, V, blank, overwrite_mode);
+        const unsigned grid = cells < (1u << 22) ? cells : (1u << 22);
+        if (aligned && V % 4 == 0)
+            k_expand_large<4><<<grid, 256, 0, stream>>>(g2, labels, xn, yn, scale, dense, cells, T, U, V, blank,
+                                                        overwrite_mode);
+        else
+            k_expand_large<1><<<grid, 256, 0, stream>>>(g2, labels, xn, yn, scale, dense, cells, T, U, V, blank,
+                                                        overwrite_mode);
     }
     return hipGetLastError();
 }
