@@ -208,11 +208,20 @@ def main():
             warp_rnnt.rnnt_loss(torch.log_softmax(xg, -1), ys, xn, yn, gather=gather, fastemit_lambda=lam,
                                 reduction="sum").backward()
 
+        from warp_rnnt_amd.functional import log_softmax as native_log_softmax
+
+        def native_chain():
+            xg.grad = None
+            warp_rnnt.rnnt_loss(native_log_softmax(xg), ys, xn, yn, gather=gather, fastemit_lambda=lam,
+                                reduction="sum").backward()
+
         def fused():
             xg.grad = None
             rnnt_loss_from_logits(xg, ys, xn, yn, fastemit_lambda=lam, reduction="sum").backward()
 
-        for name, fn in (("train_step_torch_log_softmax_chain_ms", chain), ("train_step_fused_logits_ms", fused)):
+        for name, fn in (("train_step_torch_log_softmax_chain_ms", chain),
+                         ("train_step_native_log_softmax_chain_ms", native_chain),
+                         ("train_step_fused_logits_ms", fused)):
             fn()
             torch.cuda.synchronize()
             a0, a1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -150,6 +150,11 @@ rnntStatus_t rnnt_amd_logits_backward(rnntStream_t stream, const float *logits, 
 /* Row-wise log-softmax over the last axis; out may alias x. */
 rnntStatus_t rnnt_amd_log_softmax(rnntStream_t stream, const float *x, float *out, int64_t rows, int V);
 
+/* Backward of the row-wise log-softmax: grad_in = grad_out - exp(out) * rowsum(grad_out), where
+ * `out` holds the log-probabilities the forward produced.  grad_in may alias grad_out. */
+rnntStatus_t rnnt_amd_log_softmax_backward(rnntStream_t stream, const float *grad_out, const float *out,
+                                           float *grad_in, int64_t rows, int V);
+
 /* (N,T,U,V) log-probs -> (N,T,U,2) row-major gathered log-probs (the tensor the reference's
  * wrapper hands to the native op, __init__.py:122-126).  `workspace` as for rnnt_amd_loss. */
 rnntStatus_t rnnt_amd_gather(rnntStream_t stream, const float *log_probs, const int *labels,

@@ -80,7 +80,9 @@ def test_log_softmax_then_loss_matches_fused_from_logits():
                       ops.GRADS_GATHERED, 0, 0.0)
     c2, g2 = ops.loss(x, T(labels), T(xn), T(yn), ops.IN_LOGITS_DENSE, ops.GRADS_GATHERED, 0, 0.0)
     np.testing.assert_allclose(c1.cpu().numpy(), c2.cpu().numpy(), rtol=1e-6)
-    np.testing.assert_allclose(g1.cpu().numpy(), g2.cpu().numpy(), atol=1e-5)
+    # the two routes may differ by an ulp in the log-probs, which the lattice turns into ~1e-5
+    # relative differences of the gradients (|alpha+beta| ~ 1e2 here)
+    np.testing.assert_allclose(g1.cpu().numpy(), g2.cpu().numpy(), atol=1e-4)
 
 
 def test_sharded_loss_single_process():
@@ -170,3 +172,17 @@ def test_hip_graph_capture_and_replay():
     ref = oracle.rnnt_loss_f32(lp, labels, xn, yn, scan_mode=1)
     np.testing.assert_allclose(loss.item(), ref["costs"].sum(), rtol=1e-5)
     np.testing.assert_allclose(g.cpu().numpy(), ref["grads"], atol=1e-4)
+
+
+@pytest.mark.parametrize("shape", [(1000, 50), (37, 5000), (64, 1030), (5, 7, 3, 28), (11, 2)])
+def test_log_softmax_autograd(shape):
+    from warp_rnnt_amd.functional import log_softmax
+    x = (torch.randn(*shape, device=DEV) * 2).requires_grad_(True)
+    up = torch.randn(*shape, device=DEV)
+    y = log_softmax(x)
+    y.backward(up)
+    xr = x.detach().double().requires_grad_(True)
+    yr = torch.log_softmax(xr, -1)
+    yr.backward(up.double())
+    assert (y.double() - yr).abs().max().item() < 5e-6
+    assert (x.grad.double() - xr.grad).abs().max().item() < 5e-5 * max(1.0, up.abs().sum(-1).max().item() / 50)

@@ -32,6 +32,7 @@ SYMBOLS = {
     "rnnt_amd_expand_grads": (_i, [_vp] * 7 + [_i] * 6),
     "rnnt_amd_logits_backward": (_i, [_vp] * 6 + [_i] * 5),
     "rnnt_amd_log_softmax": (_i, [_vp, _vp, _vp, _i64, _i]),
+    "rnnt_amd_log_softmax_backward": (_i, [_vp, _vp, _vp, _vp, _i64, _i]),
     "rnnt_amd_gather": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i]),
     "rnnt_amd_workspace_size_compact": (_sz, [_i, _i64]),
     "rnnt_amd_loss_compact": (_i, [_vp] * 11 + [_i, _i64, _i, _i, _i, _i, _f]),

@@ -233,6 +233,14 @@ rnntStatus_t rnnt_amd_log_softmax(rnntStream_t stream, const float* x, float* ou
     return RNNT_STATUS_SUCCESS;
 }
 
+rnntStatus_t rnnt_amd_log_softmax_backward(rnntStream_t stream, const float* grad_out, const float* out,
+                                           float* grad_in, int64_t rows, int V) {
+    if (rows < 0 || V < 1) return RNNT_STATUS_INVALID_ARGUMENT;
+    if (launch_log_softmax_backward(stream, grad_out, out, grad_in, rows, V) != hipSuccess)
+        return RNNT_STATUS_PROLOGUE_FAILED;
+    return RNNT_STATUS_SUCCESS;
+}
+
 rnntStatus_t rnnt_amd_gather(rnntStream_t stream, const float* log_probs, const int* labels,
                              float* gathered, int N, int T, int U, int V, int blank) {
     if (!dims_ok(N, T, U) || V < 1 || blank < 0 || blank >= V) return RNNT_STATUS_INVALID_ARGUMENT;

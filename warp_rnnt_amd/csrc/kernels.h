@@ -41,6 +41,8 @@ hipError_t launch_grads(hipStream_t stream, const GradArgs& a, int N, int loader
 
 // prologue / epilogue streaming kernels
 hipError_t launch_log_softmax(hipStream_t stream, const float* x, float* out, int64_t rows, int V);
+hipError_t launch_log_softmax_backward(hipStream_t stream, const float* dy, const float* y, float* dx,
+                                       int64_t rows, int V);
 hipError_t launch_gather(hipStream_t stream, const float* log_probs, const int* labels, float* out2,
                          int N, int T, int U, int V, int blank, bool skewed);
 hipError_t launch_reskew(hipStream_t stream, const float* lp2_rowmajor, float* ws2, int N, int T, int U);

@@ -364,6 +364,119 @@ hipError_t launch_logits_backward(hipStream_t stream, const float* logits, const
 }
 
 // ---------------------------------------------------------------------------
+// Backward of log-softmax: dx = dy - exp(y) * sum_v(dy), y = the log-probabilities.
+// Same three shapes as the forward kernels (LDS row tiles / one row per workgroup in
+// registers / wave per row); 12V bytes per row element (read dy, read y, write dx).
+// ---------------------------------------------------------------------------
+template <int L>
+__global__ void __launch_bounds__(SM_THREADS)
+k_lsmbwd_small(const float* dy, const float* y, float* dx, int64_t rows, int V, int R, int q) {
+    extern __shared__ __attribute__((aligned(16))) float tile[];
+    float* tdy = tile;
+    float* ty = tile + (size_t)R * V;
+    const int tid = threadIdx.x;
+    const int64_t row0 = (int64_t)blockIdx.x * R;
+    const int nrows = (int)min((int64_t)R, rows - row0);
+    const int nel = nrows * V, nvec = nel >> 2;
+    const float* sdy = dy + row0 * V;
+    const float* sy = y + row0 * V;
+    for (int i = tid; i < nvec; i += SM_THREADS) {
+        reinterpret_cast<float4*>(tdy)[i] = reinterpret_cast<const float4*>(sdy)[i];
+        reinterpret_cast<float4*>(ty)[i] = reinterpret_cast<const float4*>(sy)[i];
+    }
+    for (int e = (nvec << 2) + tid; e < nel; e += SM_THREADS) { tdy[e] = sdy[e]; ty[e] = sy[e]; }
+    __syncthreads();
+    constexpr int RPP = SM_THREADS / L;
+    const int h = tid % L, rr = tid / L;
+    const int ctail = h + (q - 1) * L;
+    const bool tail_ok = ctail < V;
+    for (int r = rr; r < nrows; r += RPP) {
+        float* rdy = tdy + r * V;
+        const float* ry = ty + r * V;
+        float s = 0.0f;
+        for (int i = 0, c = h; i < q - 1; ++i, c += L) s += rdy[c];
+        if (tail_ok) s += rdy[ctail];
+        s = group_sum<L>(s);
+        for (int i = 0, c = h; i < q - 1; ++i, c += L)
+            rdy[c] = __builtin_fmaf(-__builtin_amdgcn_exp2f(ry[c] * LOG2E), s, rdy[c]);
+        if (tail_ok) rdy[ctail] = __builtin_fmaf(-__builtin_amdgcn_exp2f(ry[ctail] * LOG2E), s, rdy[ctail]);
+    }
+    __syncthreads();
+    float* dst = dx + row0 * V;
+    for (int i = tid; i < nvec; i += SM_THREADS)
+        reinterpret_cast<float4*>(dst)[i] = reinterpret_cast<const float4*>(tdy)[i];
+    for (int e = (nvec << 2) + tid; e < nel; e += SM_THREADS) dst[e] = tdy[e];
+}
+
+__global__ void __launch_bounds__(LG_THREADS)
+k_lsmbwd_large(const float* dy, const float* y, float* dx, int64_t rows, int V) {
+    __shared__ float red[LG_THREADS / WAVE];
+    const int nvec = V >> 2;
+    for (size_t row = blockIdx.x; row < (size_t)rows; row += gridDim.x) {
+        const float4* sdy = reinterpret_cast<const float4*>(dy + row * V);
+        const float4* sy = reinterpret_cast<const float4*>(y + row * V);
+        float4 g[LG_MAXVEC];
+        float s = 0.0f;
+#pragma unroll
+        for (int i = 0; i < LG_MAXVEC; ++i) {
+            const int j = threadIdx.x + i * LG_THREADS;
+            if (j < nvec) { g[i] = sdy[j]; s += (g[i].x + g[i].y) + (g[i].z + g[i].w); }
+        }
+        s = block_reduce(s, false, red);
+        float4* dst = reinterpret_cast<float4*>(dx + row * V);
+#pragma unroll
+        for (int i = 0; i < LG_MAXVEC; ++i) {
+            const int j = threadIdx.x + i * LG_THREADS;
+            if (j < nvec) {
+                const float4 p = sy[j];
+                dst[j] = make_float4(__builtin_fmaf(-__builtin_amdgcn_exp2f(p.x * LOG2E), s, g[i].x),
+                                     __builtin_fmaf(-__builtin_amdgcn_exp2f(p.y * LOG2E), s, g[i].y),
+                                     __builtin_fmaf(-__builtin_amdgcn_exp2f(p.z * LOG2E), s, g[i].z),
+                                     __builtin_fmaf(-__builtin_amdgcn_exp2f(p.w * LOG2E), s, g[i].w));
+            }
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256)
+k_lsmbwd_generic(const float* dy, const float* y, float* dx, int64_t rows, int V) {
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    const float* g = dy + row * V;
+    const float* p = y + row * V;
+    float s = 0.0f;
+    for (int c = lane; c < V; c += WAVE) s += g[c];
+    s = group_sum<WAVE>(s);
+    float* o = dx + row * V;
+    for (int c = lane; c < V; c += WAVE) o[c] = g[c] - expf(p[c]) * s;
+}
+
+hipError_t launch_log_softmax_backward(hipStream_t stream, const float* dy, const float* y, float* dx,
+                                       int64_t rows, int V) {
+    if (rows <= 0) return hipSuccess;
+    const bool aligned = reinterpret_cast<uintptr_t>(dy) % 16 == 0 && reinterpret_cast<uintptr_t>(y) % 16 == 0 &&
+                         reinterpret_cast<uintptr_t>(dx) % 16 == 0;
+    if (aligned && V <= 1024) {
+        int L = 1;
+        while (L < 64 && L * 16 < V) L <<= 1;
+        const int q = (V + L - 1) / L;
+        int R = (SM_FLOATS / V) / 4 * 4;
+        if (R < 4) R = 4;
+        const size_t lds = (size_t)R * V * sizeof(float) * 2;
+        const unsigned grid = (unsigned)((rows + R - 1) / R);
+#define LSMB_SMALL(LL) case LL: k_lsmbwd_small<LL><<<grid, SM_THREADS, lds, stream>>>(dy, y, dx, rows, V, R, q); break;
+        switch (L) { LSMB_SMALL(1) LSMB_SMALL(2) LSMB_SMALL(4) LSMB_SMALL(8) LSMB_SMALL(16) LSMB_SMALL(32) LSMB_SMALL(64) }
+#undef LSMB_SMALL
+    } else if (aligned && V % 4 == 0 && V <= LG_THREADS * 4 * LG_MAXVEC) {
+        k_lsmbwd_large<<<(unsigned)(rows < (1 << 22) ? rows : (1 << 22)), LG_THREADS, 0, stream>>>(dy, y, dx, rows, V);
+    } else {
+        k_lsmbwd_generic<<<(unsigned)((rows + 3) / 4), 256, 0, stream>>>(dy, y, dx, rows, V);
+    }
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
 // To-diagonal kernels: dense log-probs (gather) or row-major pairs (re-layout) ->
 // diagonal-major (blank,label) pairs.  A workgroup owns a 32x32 (t,u) tile of one
 // utterance: it reads the tile with lanes along u (the contiguous axis of the

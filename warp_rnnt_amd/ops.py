@@ -157,3 +157,18 @@ def logits_backward(logits, labels, grads_diagonal, grad_costs, blank=0, out=Non
                                           grads_diagonal.data_ptr(), _ptr(grad_costs), out.data_ptr(),
                                           N, T, U, V, blank))
     return out
+
+
+def log_softmax_backward(grad_out, out, grad_in=None):
+    """grad_in = grad_out - exp(out) * rowsum(grad_out) (rows = everything but the last axis)."""
+    L = _lib.load()
+    assert grad_out.is_cuda and grad_out.dtype == torch.float32 and grad_out.is_contiguous()
+    assert out.is_contiguous() and out.shape == grad_out.shape and out.dtype == torch.float32
+    if grad_in is None:
+        grad_in = torch.empty_like(grad_out)
+    V = out.shape[-1]
+    rows = out.numel() // max(V, 1)
+    with torch.cuda.device(out.device):
+        _check(L.rnnt_amd_log_softmax_backward(_stream(out.device), grad_out.data_ptr(), out.data_ptr(),
+                                               grad_in.data_ptr(), rows, V))
+    return grad_in
