@@ -9,6 +9,7 @@ difference the survey asked for: `--warmup` untimed iterations first (default 1;
     python tools/benchmark_table.py --loss warp-rnnt-gather [--random_length] [--markdown out.md]
 
 --loss: warp-rnnt | warp-rnnt-gather            rnnt_loss(log_softmax(xs), ..., gather=False|True)
+        warp-rnnt-compact                       rnnt_loss(log_softmax(xs) packed, ..., compact=True)
         warp-rnnt-fused                         rnnt_loss_from_logits(xs, ...) (no counterpart in the reference)
         torch-log-softmax-gather                F.log_softmax from torch + rnnt_loss(gather=True)
 """
@@ -73,6 +74,10 @@ def main():
     elif a.loss == "torch-log-softmax-gather":
         def run_loss(xs, ys, xn, yn):
             return warp_rnnt.rnnt_loss(torch.log_softmax(xs, -1), ys, xn, yn, gather=True)
+    elif a.loss == "warp-rnnt-compact":
+        def run_loss(xs, ys, xn, yn):       # full lengths: the packed layout is a reshape
+            lp = ops.log_softmax(xs.detach())
+            return warp_rnnt.rnnt_loss(lp.view(-1, lp.size(-1)), ys.reshape(-1).contiguous(), xn, yn, compact=True)
     elif a.loss == "warp-rnnt-fused":
         def run_loss(xs, ys, xn, yn):
             return rnnt_loss_from_logits(xs, ys, xn, yn)
