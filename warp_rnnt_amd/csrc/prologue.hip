@@ -112,6 +112,7 @@ k_lsm_small(const float* x, float* out, const int* __restrict__ labels,
             int64_t rows, int V, int R, int q, int T, int U, int blank, LsmBwd bw) {
     constexpr bool GATHER = MODE == LSM_GATHER;
     extern __shared__ __attribute__((aligned(16))) float tile[];
+    float2* stat = reinterpret_cast<float2*>(tile + (size_t)R * V);   // GATHER: (max, log-sum) per row
     const int tid = threadIdx.x;
     const int64_t row0 = (int64_t)blockIdx.x * R;
     const int nrows = (int)min((int64_t)R, rows - row0);
@@ -143,11 +144,7 @@ k_lsm_small(const float* x, float* out, const int* __restrict__ labels,
         s = group_sum<L>(s);
         const float ls = __builtin_amdgcn_logf(s) * LN2;
         if constexpr (GATHER) {
-            if (h == 0) {
-                const CellMap m = map_cell((size_t)(row0 + r), labels, T, U, blank);
-                reinterpret_cast<float2*>(out)[m.sk] =
-                    make_float2((row[blank] - mx) - ls, (row[m.label] - mx) - ls);
-            }
+            if (h == 0) stat[r] = make_float2(mx, ls);
         } else if constexpr (MODE == LSM_BWD) {
             const CellMap m = map_cell((size_t)(row0 + r), labels, T, U, blank);
             const float sc = bw.scale ? bw.scale[m.n] : 1.0f;
@@ -164,7 +161,18 @@ k_lsm_small(const float* x, float* out, const int* __restrict__ labels,
             if (tail_ok) row[ctail] = (row[ctail] - mx) - ls;
         }
     }
-    if constexpr (!GATHER) {
+    if constexpr (GATHER) {
+        // one lane per row with all lanes busy (the per-row index arithmetic costs ~60 instructions;
+        // doing it inside the L-lane row loop ran it with a quarter of the lanes)
+        __syncthreads();
+        for (int r = tid; r < nrows; r += SM_THREADS) {
+            const CellMap m = map_cell((size_t)(row0 + r), labels, T, U, blank);
+            const float2 st = stat[r];
+            const float* row = tile + r * V;
+            reinterpret_cast<float2*>(out)[m.sk] =
+                make_float2((row[blank] - st.x) - st.y, (row[m.label] - st.x) - st.y);
+        }
+    } else {
         __syncthreads();
         float* dst = out + row0 * V;
         for (int i = tid; i < nvec; i += SM_THREADS)
@@ -324,7 +332,7 @@ static hipError_t dispatch_lsm(hipStream_t stream, const float* x, float* out, c
         const int rpp = SM_THREADS / L;                // rows per pass, a multiple of 4
         int R = (SM_FLOATS / V) / rpp * rpp;           // whole passes
         if (R < rpp) R = rpp;
-        const size_t lds = (size_t)R * V * sizeof(float);
+        const size_t lds = (size_t)R * V * sizeof(float) + (GATHER ? (size_t)R * sizeof(float2) : 0);
         const unsigned grid = (unsigned)((rows + R - 1) / R);
 #define LSM_SMALL(LL)                                                                           \
     case LL:                                                                                    \
