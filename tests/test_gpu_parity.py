@@ -302,3 +302,54 @@ def test_shape_fuzz_vs_oracle():
         c, g = run_native(lp, labels, xn, yn, blank=0, lam=lam)
         np.testing.assert_allclose(c, ref["costs"], rtol=COST_RTOL, err_msg=f"case {N},{T},{U},{V}")
         np.testing.assert_allclose(g, ref["grads"], atol=GRAD_ATOL, err_msg=f"case {N},{T},{U},{V}")
+
+
+# ----------------------------------------------------------------------------
+# 8. BASELINE config-3 / config-2 shapes at full size, invariants + oracle
+# ----------------------------------------------------------------------------
+def test_config3_full_size_from_logits():
+    """N=32,T=150,U=20,V=5000 (large-vocabulary kernels): fused logits entry vs oracle."""
+    from warp_rnnt_amd import ops
+    N, T, U, V = 32, 150, 20, 5000
+    logits, labels, xn, yn = make_case(3, N, T, U, V)
+    costs, g2 = ops.loss(t32(logits), t32(labels), t32(xn), t32(yn), ops.IN_LOGITS_DENSE, ops.GRADS_GATHERED,
+                         0, 0.0)
+    lp = oracle.log_softmax_f32(logits)
+    ref = oracle.rnnt_loss_f32(oracle.gather_f32(lp, labels, 0), labels, xn, yn, blank=-1, scan_mode=1)
+    np.testing.assert_allclose(costs.cpu().numpy(), ref["costs"], rtol=COST_RTOL)
+    g = g2.cpu().numpy()
+    # |alpha| reaches ~1.3e3 here (log-probs ~ -8.5): one fp32 ulp there is 1.2e-4, so two fp32
+    # implementations whose log-softmax differs in the last bit disagree by a few 1e-4 in the
+    # gradients.  Judge both against exact arithmetic instead.
+    lp64 = transduce_np.log_softmax(logits)
+    c64, g64 = transduce_np.transduce_batch(lp64, labels, xn, yn, fast=True)
+    idx = np.zeros((N, T, U, 2), dtype=np.int64)
+    idx[:, :, :U - 1, 1] = labels[:, None, :]
+    g64_2 = np.take_along_axis(g64, idx, axis=3)
+    g64_2[:, :, U - 1, 1] = 0
+    err_hip, err_ora = np.abs(g - g64_2).max(), np.abs(ref["grads"] - g64_2).max()
+    print(f"config3: max |grad - fp64|: hip {err_hip:.2e}, fp32 oracle {err_ora:.2e}")
+    assert err_hip < 2e-3 and err_hip < 3.0 * err_ora + 2e-4
+    np.testing.assert_allclose(costs.cpu().numpy(), c64, rtol=2e-6)
+    np.testing.assert_allclose(g[..., 0].sum(axis=2), -1.0, atol=2e-3)
+    np.testing.assert_allclose(g[:, :, :-1, 1].sum(axis=1), -1.0, atol=2e-3)
+
+
+def test_status_codes_for_bad_arguments():
+    """The C ABI rejects unusable arguments before any launch (status 5), the Python layer raises."""
+    import warp_rnnt_amd
+    import warp_rnnt._C as core
+    L = warp_rnnt_amd.load()
+    assert L.rnnt_amd_loss(None, None, 0, None, None, None, None, None, None, 0, 1, 1, 1, 1, 0, 0.0) == 5
+    assert L.run_warp_rnnt(None, None, None, None, None, None, None, None, None, None, 1, 0, 1, 1, 0, 0.0) == 5
+    assert L.run_warp_rnnt(None, None, None, None, None, None, None, None, None, None, 1, 1, 1, 4, 7, 0.0) == 5
+    assert L.rnnt_amd_log_softmax(None, None, None, -1, 3) == 5
+    x = torch.zeros((1, 2, 2, 3), device=dev())
+    ys = torch.zeros((1, 1), dtype=torch.int, device=dev())
+    one = torch.ones((1,), dtype=torch.int, device=dev())
+    with pytest.raises(RuntimeError, match="rnnt_loss status 5"):
+        core.rnnt_loss(x, ys, one, one, blank=3)
+    c, g = core.rnnt_loss(torch.zeros((0, 2, 2, 3), device=dev()), torch.zeros((0, 1), dtype=torch.int, device=dev()),
+                          torch.zeros((0,), dtype=torch.int, device=dev()),
+                          torch.zeros((0,), dtype=torch.int, device=dev()))
+    assert c.shape == (0,) and g.shape == (0, 2, 2, 3)
