@@ -57,14 +57,42 @@ __device__ __forceinline__ ExpandCell expand_cell(unsigned cell, const float2* _
     return c;
 }
 
+// Row sources: where row `i` of the dense output gets its two values from.
+struct PaddedRows {    // (N,T,U,V) output, diagonal-major pairs (gather backward / dense forward)
+    const float2* g2; const int* labels; const int* xn; const int* yn; const float* scale;
+    int T, U, blank, overwrite;
+    __device__ __forceinline__ ExpandCell operator()(unsigned row) const {
+        return expand_cell(row, g2, labels, xn, yn, scale, T, U, blank, overwrite);
+    }
+};
+struct CompactRows {   // (STU,V) output, row-major pairs + loc (core_compact.cu:456-484)
+    const float2* g2; const int64_t* loc; const int* cum_lens; const float* grad_cost;
+    int N, blank;
+    __device__ __forceinline__ ExpandCell operator()(unsigned row) const {
+        // utterance of this row: first n with cum_lens[n] > row (inclusive prefix sums)
+        int lo = 0, hi = N - 1;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if ((unsigned)cum_lens[mid] > row) hi = mid; else lo = mid + 1;
+        }
+        const float sc = grad_cost[lo];
+        const float2 g = g2[row];
+        ExpandCell c;
+        c.gB = g.x * sc;
+        c.gL = g.y * sc;
+        c.lab = (int)loc[row];
+        if (c.lab == blank) c.lab = -1;        // the reference writes the label slot only if loc != blank
+        return c;
+    }
+};
+
 // ---- V <= 1024: R whole rows per workgroup through LDS ----
 constexpr int EX_THREADS = 256;
 constexpr int EX_FLOATS = 3200;
 
+template <typename Rows>
 __global__ void __launch_bounds__(EX_THREADS)
-k_expand_small(const float2* __restrict__ g2, const int* __restrict__ labels, const int* __restrict__ xn,
-               const int* __restrict__ yn, const float* __restrict__ scale, float* __restrict__ dense,
-               unsigned cells, int R, int T, int U, int V, int blank, int overwrite) {
+k_expand_small(const Rows rows, float* __restrict__ dense, unsigned cells, int R, int V, int blank) {
     extern __shared__ __attribute__((aligned(16))) float tile[];
     const int tid = threadIdx.x;
     const unsigned cell0 = blockIdx.x * (unsigned)R;
@@ -76,7 +104,7 @@ k_expand_small(const float2* __restrict__ g2, const int* __restrict__ labels, co
     for (int e = (nvec << 2) + tid; e < nel; e += EX_THREADS) tile[e] = 0.f;
     __syncthreads();
     for (int r = tid; r < nrows; r += EX_THREADS) {
-        const ExpandCell c = expand_cell(cell0 + r, g2, labels, xn, yn, scale, T, U, blank, overwrite);
+        const ExpandCell c = rows(cell0 + r);
         float* row = tile + r * V;
         row[blank] = c.gB;
         if (c.lab >= 0) row[c.lab] += c.gL;     // scatter-add semantics when label == blank (sum mode)
@@ -89,13 +117,11 @@ k_expand_small(const float2* __restrict__ g2, const int* __restrict__ labels, co
 }
 
 // ---- larger V: one row per workgroup iteration, zeros from registers ----
-template <int VEC>
+template <int VEC, typename Rows>
 __global__ void __launch_bounds__(256)
-k_expand_large(const float2* __restrict__ g2, const int* __restrict__ labels, const int* __restrict__ xn,
-               const int* __restrict__ yn, const float* __restrict__ scale, float* __restrict__ dense,
-               unsigned cells, int T, int U, int V, int blank, int overwrite) {
+k_expand_large(const Rows rows, float* __restrict__ dense, unsigned cells, int V, int blank) {
     for (unsigned cell = blockIdx.x; cell < cells; cell += gridDim.x) {
-        const ExpandCell c = expand_cell(cell, g2, labels, xn, yn, scale, T, U, blank, overwrite);
+        const ExpandCell c = rows(cell);
         float* dst = dense + (size_t)cell * V;
         for (int v0 = threadIdx.x * VEC; v0 < V; v0 += 256 * VEC) {
             float o[VEC];
@@ -110,30 +136,42 @@ k_expand_large(const float2* __restrict__ g2, const int* __restrict__ labels, co
     }
 }
 
-hipError_t launch_expand(hipStream_t stream, const float* g2_skewed, const int* labels, const int* xn,
-                         const int* yn, const float* scale, float* dense, int N, int T, int U, int V,
-                         int blank, int overwrite_mode) {
-    const size_t cells64 = (size_t)N * T * U;
-    if (cells64 == 0 || V == 0) return hipSuccess;
-    const unsigned cells = (unsigned)cells64;
-    const float2* g2 = reinterpret_cast<const float2*>(g2_skewed);
+template <typename Rows>
+static hipError_t launch_rows(hipStream_t stream, const Rows& rows, float* dense, unsigned cells, int V, int blank) {
     const bool aligned = reinterpret_cast<uintptr_t>(dense) % 16 == 0;
     if (aligned && V <= 1024) {
         int R = (EX_FLOATS / V) / 4 * 4;          // R % 4 == 0 keeps every tile start 16-byte aligned
         if (R < 4) R = 4;
         const size_t lds = (size_t)R * V * sizeof(float);
-        k_expand_small<<<(cells + R - 1) / R, EX_THREADS, lds, stream>>>(g2, labels, xn, yn, scale, dense, cells,
-                                                                          R, T, U, V, blank, overwrite_mode);
+        k_expand_small<Rows><<<(cells + R - 1) / R, EX_THREADS, lds, stream>>>(rows, dense, cells, R, V, blank);
     } else {
         const unsigned grid = cells < (1u << 22) ? cells : (1u << 22);
         if (aligned && V % 4 == 0)
-            k_expand_large<4><<<grid, 256, 0, stream>>>(g2, labels, xn, yn, scale, dense, cells, T, U, V, blank,
-                                                        overwrite_mode);
+            k_expand_large<4, Rows><<<grid, 256, 0, stream>>>(rows, dense, cells, V, blank);
         else
-            k_expand_large<1><<<grid, 256, 0, stream>>>(g2, labels, xn, yn, scale, dense, cells, T, U, V, blank,
-                                                        overwrite_mode);
+            k_expand_large<1, Rows><<<grid, 256, 0, stream>>>(rows, dense, cells, V, blank);
     }
     return hipGetLastError();
+}
+
+hipError_t launch_expand(hipStream_t stream, const float* g2_skewed, const int* labels, const int* xn,
+                         const int* yn, const float* scale, float* dense, int N, int T, int U, int V,
+                         int blank, int overwrite_mode) {
+    const size_t cells64 = (size_t)N * T * U;
+    if (cells64 == 0 || V == 0) return hipSuccess;
+    const PaddedRows rows{reinterpret_cast<const float2*>(g2_skewed), labels, xn, yn, scale, T, U, blank,
+                          overwrite_mode};
+    return launch_rows(stream, rows, dense, (unsigned)cells64, V, blank);
+}
+
+// (STU,V) gradient rows of the compact layout; replaces the first version in prologue.hip
+hipError_t launch_scatter_compact(hipStream_t stream, const float* grad_cost, const float* grads2,
+                                  const int64_t* loc, const int* cum_lens, float* out, int64_t STU, int N,
+                                  int V, int blank) {
+    if (STU <= 0 || V <= 0) return hipSuccess;
+    if (STU >= ((int64_t)1 << 32)) return hipErrorInvalidValue;
+    const CompactRows rows{reinterpret_cast<const float2*>(grads2), loc, cum_lens, grad_cost, N, blank};
+    return launch_rows(stream, rows, out, (unsigned)STU, V, blank);
 }
 
 }  // namespace rnnt

@@ -652,63 +652,4 @@ hipError_t launch_gather_compact(hipStream_t stream, const float* xs, const int*
     return hipGetLastError();
 }
 
-// scatter_grad[i, blank] = g[i,0]*grad_cost[n(i)];  if loc[i] != blank: scatter_grad[i, loc[i]] = g[i,1]*grad_cost[n(i)]
-// Every output row is written once in full (the reference zero-fills (STU,V) and then does two
-// scattered writes per row).  A workgroup owns 4096 consecutive floats of the output.
-template <int VEC>
-__global__ void __launch_bounds__(256)
-k_scatter_compact(const float* __restrict__ grad_cost, const float2* __restrict__ g2,
-                  const int64_t* __restrict__ loc, const int* __restrict__ cum_lens, float* __restrict__ out,
-                  int64_t total, int N, int V, int blank) {
-    const int64_t base = (int64_t)blockIdx.x * 256 * VEC;
-    const int64_t row0 = base / V;                      // one 64-bit division per workgroup
-    const unsigned el = (unsigned)(base - row0 * V) + threadIdx.x * VEC;
-    int64_t row = row0 + el / (unsigned)V;
-    int v = el % (unsigned)V;
-    if (base + (int64_t)threadIdx.x * VEC >= total) return;
-    float vals[VEC];
-    int64_t crow = -1;
-    float gB = 0.f, gL = 0.f;
-    int lab = -1;
-#pragma unroll
-    for (int j = 0; j < VEC; ++j) {
-        if (row != crow) {
-            crow = row;
-            // utterance of this row: first n with cum_lens[n] > row (inclusive prefix sums)
-            int lo = 0, hi = N - 1;
-            while (lo < hi) {
-                const int mid = (lo + hi) >> 1;
-                if ((int64_t)cum_lens[mid] > row) hi = mid; else lo = mid + 1;
-            }
-            const float sc = grad_cost[lo];
-            const float2 g = g2[row];
-            gB = g.x * sc; gL = g.y * sc;
-            lab = (int)loc[row];
-        }
-        vals[j] = (v == blank) ? gB : ((v == lab) ? gL : 0.0f);
-        if (++v == V) { v = 0; ++row; }
-    }
-    float* dst = out + base + (int64_t)threadIdx.x * VEC;
-    if constexpr (VEC == 4) *reinterpret_cast<float4*>(dst) = make_float4(vals[0], vals[1], vals[2], vals[3]);
-    else dst[0] = vals[0];
-}
-
-hipError_t launch_scatter_compact(hipStream_t stream, const float* grad_cost, const float* grads2,
-                                  const int64_t* loc, const int* cum_lens, float* out, int64_t STU, int N,
-                                  int V, int blank) {
-    const int64_t total = STU * V;
-    if (total <= 0) return hipSuccess;
-    const bool vec = (total % 4 == 0) && (reinterpret_cast<uintptr_t>(out) % 16 == 0);
-    const int64_t per_block = vec ? 1024 : 256;
-    const int64_t nblk = (total + per_block - 1) / per_block;
-    if (nblk >= ((int64_t)1 << 31)) return hipErrorInvalidValue;
-    if (vec)
-        k_scatter_compact<4><<<(unsigned)nblk, 256, 0, stream>>>(grad_cost, reinterpret_cast<const float2*>(grads2),
-                                                                  loc, cum_lens, out, total, N, V, blank);
-    else
-        k_scatter_compact<1><<<(unsigned)nblk, 256, 0, stream>>>(grad_cost, reinterpret_cast<const float2*>(grads2),
-                                                                  loc, cum_lens, out, total, N, V, blank);
-    return hipGetLastError();
-}
-
 }  // namespace rnnt
