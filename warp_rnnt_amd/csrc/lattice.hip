@@ -411,8 +411,16 @@ template <int LOADER, bool COMPACT>
 __global__ void __launch_bounds__(MAXW * WAVE) k_lattice(const LatticeArgs a) {
     __shared__ float mail[MAXW][RING];
     __shared__ float trash[MAXW][MAIL_TRASH];
-    const int n = blockIdx.x >> 1;
-    if (blockIdx.x & 1)
+    // XCD-aware placement: workgroup b runs on XCD b % 8 (MI355X_MICROARCH.md), each XCD has its
+    // own L2.  The alpha and the beta sweep of one utterance read the same diagonal-major plane
+    // (from opposite ends), so they are given ids b and b+8: same XCD, shared L2 lines.
+    // (Speed only; nothing depends on the placement.)
+    const unsigned b = blockIdx.x, pairs_total = gridDim.x >> 1;
+    const unsigned grp = b >> 4, in = b & 15;
+    unsigned n, dir;
+    if ((grp << 3) + 8 <= pairs_total) { n = (grp << 3) + (in & 7); dir = in >> 3; }
+    else { const unsigned r = b - (grp << 4); n = (grp << 3) + (r >> 1); dir = r & 1; }   // tail group
+    if (dir)
         sweep<LOADER, true, COMPACT>(a, n, mail, trash);
     else
         sweep<LOADER, false, COMPACT>(a, n, mail, trash);

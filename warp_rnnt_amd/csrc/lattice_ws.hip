@@ -325,8 +325,16 @@ template <bool COMPACT>
 __global__ void __launch_bounds__(2 * MAXA * WAVE) k_lattice_ws(const LatticeArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     Smem* smem = reinterpret_cast<Smem*>(smem_raw);
-    const int n = blockIdx.x >> 1;
-    if (blockIdx.x & 1)
+    // XCD-aware placement: workgroup b runs on XCD b % 8 (MI355X_MICROARCH.md), each XCD has its
+    // own L2.  The alpha and the beta sweep of one utterance read the same diagonal-major plane
+    // (from opposite ends), so they are given ids b and b+8: same XCD, shared L2 lines.
+    // (Speed only; nothing depends on the placement.)
+    const unsigned b = blockIdx.x, pairs_total = gridDim.x >> 1;
+    const unsigned grp = b >> 4, in = b & 15;
+    unsigned n, dir;
+    if ((grp << 3) + 8 <= pairs_total) { n = (grp << 3) + (in & 7); dir = in >> 3; }
+    else { const unsigned r = b - (grp << 4); n = (grp << 3) + (r >> 1); dir = r & 1; }   // tail group
+    if (dir)
         sweep<true, COMPACT>(a, n, smem);
     else
         sweep<false, COMPACT>(a, n, smem);
