@@ -51,6 +51,10 @@ typedef enum {
  *     return unspecified (alphas/betas hold the lattices in diagonal-major order,
  *     counts[n*2U] holds the alpha-side log-likelihood bits).  counts need not be zeroed.
  *   costs (N,): out.
+ * Lengths: the reference does not check 1 <= xn[n] <= T, 0 <= yn[n] <= U-1 (binding.cpp:47-51)
+ *   and reads out of range when they are violated.  Every entry point of this library checks
+ *   them on the device (no host sync): an offending utterance gets costs[n] = NaN and no
+ *   gradient (zeros), the rest of the batch is unaffected.
  */
 rnntStatus_t run_warp_rnnt(rnntStream_t stream, unsigned int *counts, float *alphas, float *betas,
                            const int *labels, const float *log_probs, float *grads, float *costs,

@@ -353,3 +353,37 @@ def test_status_codes_for_bad_arguments():
                           torch.zeros((0,), dtype=torch.int, device=dev()),
                           torch.zeros((0,), dtype=torch.int, device=dev()))
     assert c.shape == (0,) and g.shape == (0, 2, 2, 3)
+
+
+@pytest.mark.parametrize("gather", [False, True])
+@pytest.mark.parametrize("U", [6, 130])
+def test_out_of_range_lengths_are_contained(gather, U):
+    """The reference does not check 1 <= xn <= T, 0 <= yn <= U-1 (binding.cpp:47-51) and reads out of
+    range.  Here such an utterance gets cost NaN and zero gradients; its neighbours are unaffected."""
+    import warp_rnnt._C as core
+    N, T, V = 5, 11, 7
+    logits, labels, xn, yn = make_case(77, N, T, U, V)
+    lp = np_log_softmax32(logits)
+    ref = oracle.rnnt_loss_f32(lp, labels, xn, yn, blank=0)
+    bad_x, bad_y = xn.copy(), yn.copy()
+    bad_x[0], bad_x[2], bad_y[3] = 0, T + 3, U          # utterance 4 and 1 stay valid
+    bad_y[0] = -1
+    if gather:
+        c, g = core.rnnt_loss_gather(t32(lp), t32(labels), t32(bad_x), t32(bad_y), blank=0)
+        # internal diagonal-major pairs: compare through the dense expansion
+        dense = core.rnnt_loss_gather_backward(torch.ones(N, device=dev()), g, t32(labels), t32(bad_x),
+                                               t32(bad_y), V, 0).cpu().numpy()
+        for n in (1, 4):
+            np.testing.assert_allclose(dense[n], ref["grads"][n], atol=1e-5)
+        for n in (0, 2, 3):
+            assert not dense[n].any()
+    else:
+        c, g = core.rnnt_loss(t32(lp), t32(labels), t32(bad_x), t32(bad_y), blank=0)
+        g = g.cpu().numpy()
+        for n in (1, 4):
+            np.testing.assert_allclose(g[n], ref["grads"][n], atol=1e-5)
+        for n in (0, 2, 3):
+            assert not g[n].any()
+    c = c.cpu().numpy()
+    assert np.isnan(c[[0, 2, 3]]).all()
+    np.testing.assert_allclose(c[[1, 4]], ref["costs"][[1, 4]], rtol=1e-5)

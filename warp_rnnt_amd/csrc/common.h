@@ -33,6 +33,24 @@ __device__ __forceinline__ float readlane(float v, int lane) {
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
 }
 
+// Per-utterance lengths as the kernels use them.  The reference never checks 1 <= xn <= T and
+// 0 <= yn <= U-1 (binding.cpp:47-51; xn = 0 reads index -1, core.cu:343).  Checking on the host would
+// cost a device sync, so the check lives here: an utterance with out-of-range lengths is swept as a
+// one-cell lattice (no out-of-range access) and k_grads reports cost = NaN with zero gradients.
+struct UttLens {
+    int Tn, Un;
+    bool ok;
+};
+template <bool COMPACT>
+__device__ __forceinline__ UttLens utt_lens(const int* xn, const int* yn, int n, int T, int U) {
+    const int x = xn[n], y = yn[n];
+    UttLens l;
+    l.ok = COMPACT ? (x >= 1 && y >= 0) : (x >= 1 && x <= T && y >= 0 && y < U);
+    l.Tn = l.ok ? x : 1;
+    l.Un = l.ok ? y + 1 : 1;
+    return l;
+}
+
 // How a kernel finds the blank / label log-probability of lattice cell (t,u).
 enum Loader : int {
     LOAD_SKEWED = 0,   // float2 workspace, diagonal-major (internal layout)

@@ -21,7 +21,8 @@ namespace rnnt {
 template <int LOADER, int WRITER, bool COMPACT>
 __global__ void __launch_bounds__(256) k_grads(const GradArgs a) {
     const int n = blockIdx.y;
-    const int Tn = a.xn[n], Un = a.yn[n] + 1;
+    const UttLens len = utt_lens<COMPACT>(a.xn, a.yn, n, a.T, a.U);
+    const int Tn = len.Tn, Un = len.Un;
     const int T = COMPACT ? Tn : a.T, U = COMPACT ? Un : a.U;     // compact: per-utterance planes
     const size_t nb = COMPACT ? (size_t)a.offs[n] : (size_t)n * T * U;
     const float* __restrict__ al = a.alphas + nb;
@@ -34,9 +35,9 @@ __global__ void __launch_bounds__(256) k_grads(const GradArgs a) {
     const float b00 = be[0];   // sk(0,0) = 0
     const float ll_a = a.ll[n];   // alpha[T-1,U-1] + lpB[T-1,U-1], written by the alpha sweep
     const float ratio = fabsf(ll_a - b00) / fabsf(fmaxf(ll_a, b00));
-    const bool bad = ratio > 0.001f;
+    const bool bad = ratio > 0.001f || !len.ok;
     if (idx == 0) {
-        a.costs[n] = bad ? -((ll_a + b00) / 2.0f) : -b00;
+        a.costs[n] = !len.ok ? __builtin_nanf("") : bad ? -((ll_a + b00) / 2.0f) : -b00;
         if (a.mismatch) a.mismatch[n] = bad ? 1 : 0;
     }
     if (!in) return;

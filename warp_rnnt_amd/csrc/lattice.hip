@@ -214,7 +214,8 @@ __device__ __forceinline__ void run_block(const Cell (&cur)[K], const float mvec
 template <int LOADER, bool BETA, bool COMPACT>
 __device__ __forceinline__ void sweep(const LatticeArgs& a, const int n, float (*mail)[RING],
                                       float (*trash)[MAIL_TRASH]) {
-    const int Tn = a.xn[n], Un = a.yn[n] + 1;
+    const UttLens len = utt_lens<COMPACT>(a.xn, a.yn, n, a.T, a.U);
+    const int Tn = len.Tn, Un = len.Un;
     // padded planes (N,T,U), or -- compact layout -- one (T_n,U_n) plane per utterance at offs[n]
     const int T = COMPACT ? Tn : a.T, U = COMPACT ? Un : a.U;
     const int lane = threadIdx.x & (WAVE - 1);

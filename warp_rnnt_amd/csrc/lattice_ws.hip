@@ -156,7 +156,8 @@ __device__ __forceinline__ void compute_block(const f32x2 (&cur)[K], const float
 
 template <bool BETA, bool COMPACT>
 __device__ __forceinline__ void sweep(const LatticeArgs& a, const int n, Smem* smem) {
-    const int Tn = a.xn[n], Un = a.yn[n] + 1;
+    const UttLens len = utt_lens<COMPACT>(a.xn, a.yn, n, a.T, a.U);
+    const int Tn = len.Tn, Un = len.Un;
     const int T = COMPACT ? Tn : a.T, U = COMPACT ? Un : a.U;
     const int lane = threadIdx.x & (WAVE - 1);
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
