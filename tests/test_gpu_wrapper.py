@@ -186,3 +186,58 @@ def test_log_softmax_autograd(shape):
     yr.backward(up.double())
     assert (y.double() - yr).abs().max().item() < 5e-6
     assert (x.grad.double() - xr.grad).abs().max().item() < 5e-5 * max(1.0, up.abs().sum(-1).max().item() / 50)
+
+
+# ----------------------------------------------------------------------------
+# joint network in front of the loss (examples/joint_benchmark.py; benchmark2.py:93-164)
+# ----------------------------------------------------------------------------
+def _load_joint_example():
+    import importlib.util
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "joint_benchmark.py")
+    spec = importlib.util.spec_from_file_location("joint_benchmark", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+@pytest.mark.gpu
+def test_joint_network_all_loss_paths_agree():
+    """dense, gather, compact and fused-from-logits give the same loss and the same d/df, d/dg."""
+    jb = _load_joint_example()
+    N, T, U, V, H = 4, 17, 6, 23, 32
+    torch.manual_seed(5)
+    f, g, ys, f_len, g_len = jb.make_batch(N, T, U, V, H, True, torch.device("cuda"))
+    weights = None
+    results = {}
+    for name in jb.LOSSES:
+        joint = jb.JointNetwork(H, V, packed=name.endswith("compact"), log_softmax=not name.endswith("fused")).cuda()
+        if weights is None:
+            weights = {k: v.clone() for k, v in joint.state_dict().items()}
+        joint.load_state_dict(weights)
+        ff, gg = f.clone().requires_grad_(True), g.clone().requires_grad_(True)
+        costs = jb.pick_loss(name)(joint(ff, gg, f_len, g_len), ys, f_len, g_len)
+        (costs * torch.arange(1, N + 1, device=costs.device)).sum().backward()
+        results[name] = (costs.detach().cpu().numpy(), ff.grad.cpu().numpy(), gg.grad.cpu().numpy(),
+                         joint.proj.weight.grad.cpu().numpy())
+    ref = results["warp-rnnt"]
+    for name, got in results.items():
+        np.testing.assert_allclose(got[0], ref[0], rtol=2e-5, err_msg=name)
+        for a, b in zip(got[1:], ref[1:]):
+            np.testing.assert_allclose(a, b, atol=5e-4, rtol=1e-3, err_msg=name)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("extra", [[], ["--ddp"], ["--fwd-only", "--random-length"]])
+def test_joint_benchmark_cli_runs(extra):
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29613", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    for loss in ("warp-rnnt-gather", "warp-rnnt-fused", "warp-rnnt-compact"):
+        out = subprocess.run([sys.executable, os.path.join(root, "examples", "joint_benchmark.py"), "--loss", loss,
+                              "--shapes", "20,5,11", "--batches", "3", "--iters", "2", "--warmup", "1",
+                              "--hidden", "16"] + extra, env=env, capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr[-2000:]
+        assert "| 20 | 5 | 11 | 3 |" in out.stdout
