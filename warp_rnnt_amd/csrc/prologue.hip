@@ -11,6 +11,8 @@
 //
 // Output of the gather kernels is the diagonal-major float2 workspace
 // (common.h) that the lattice sweep reads with coalesced row loads.
+#include <cstdio>
+#include <cstdlib>
 #include "common.h"
 #include "kernels.h"
 
@@ -186,9 +188,12 @@ k_lsm_small(const float* x, float* out, const int* __restrict__ labels,
 // the row lives in registers (up to 16 float4 per lane), one HBM read and one
 // HBM write per element.
 // ---------------------------------------------------------------------------
-constexpr int LG_THREADS = 256;
-constexpr int LG_MAXVEC = 16;
+// Shape of the row-per-workgroup kernel: THREADS x NV float4 must cover a row.  The registers that hold
+// the row set the residency (NV=16 x 256 threads: 84 VGPRs, 5 waves/SIMD; NV=8: 8 waves/SIMD), so the
+// launcher picks the smallest cover: V <= 4096: 256x4, V <= 8192: 256x8, V <= 16384: 512x8.
+constexpr int LG_MAXV = 16384;
 
+template <int THREADS>
 __device__ __forceinline__ float block_reduce(float v, bool is_max, float* red) {
     v = is_max ? group_max<WAVE>(v) : group_sum<WAVE>(v);
     const int w = threadIdx.x >> 6;
@@ -197,11 +202,11 @@ __device__ __forceinline__ float block_reduce(float v, bool is_max, float* red) 
     __syncthreads();
     float r = red[0];
 #pragma unroll
-    for (int i = 1; i < LG_THREADS / WAVE; ++i) r = is_max ? fmaxf(r, red[i]) : r + red[i];
+    for (int i = 1; i < THREADS / WAVE; ++i) r = is_max ? fmaxf(r, red[i]) : r + red[i];
     return r;
 }
 
-template <int MODE>
+template <int MODE, int LG_THREADS, int LG_MAXVEC>
 __global__ void __launch_bounds__(LG_THREADS)
 k_lsm_large(const float* x, float* out, const int* __restrict__ labels,
             int64_t rows, int V, int T, int U, int blank, LsmBwd bw) {
@@ -220,7 +225,7 @@ k_lsm_large(const float* x, float* out, const int* __restrict__ labels,
             mx = fmaxf(fmaxf(mx, fmaxf(v[i].x, v[i].y)), fmaxf(v[i].z, v[i].w));
         }
     }
-    mx = block_reduce(mx, true, red);
+    mx = block_reduce<LG_THREADS>(mx, true, red);
     const float mb = -mx * LOG2E;
     float s = 0.0f;
 #pragma unroll
@@ -230,7 +235,7 @@ k_lsm_large(const float* x, float* out, const int* __restrict__ labels,
             s += (__builtin_amdgcn_exp2f(__builtin_fmaf(v[i].x, LOG2E, mb)) + __builtin_amdgcn_exp2f(__builtin_fmaf(v[i].y, LOG2E, mb))) +
                  (__builtin_amdgcn_exp2f(__builtin_fmaf(v[i].z, LOG2E, mb)) + __builtin_amdgcn_exp2f(__builtin_fmaf(v[i].w, LOG2E, mb)));
     }
-    s = block_reduce(s, false, red);
+    s = block_reduce<LG_THREADS>(s, false, red);
     const float ls = logf(s);
     if constexpr (GATHER) {
         if (threadIdx.x == 0) {
@@ -344,9 +349,23 @@ static hipError_t dispatch_lsm(hipStream_t stream, const float* x, float* out, c
             LSM_SMALL(64)
         }
 #undef LSM_SMALL
-    } else if (aligned && V % 4 == 0 && V <= LG_THREADS * 4 * LG_MAXVEC) {
-        k_lsm_large<MODE><<<(unsigned)(rows < (1 << 22) ? rows : (1 << 22)), LG_THREADS, 0, stream>>>(
-            x, out, labels, rows, V, T, U, blank, bw);
+    } else if (aligned && V % 4 == 0 && V <= LG_MAXV) {
+        const unsigned grid = (unsigned)(rows < (1 << 22) ? rows : (1 << 22));
+#ifdef RNNT_LG_PROBE
+        if (const char* e = getenv("RNNT_LG_VARIANT")) {
+            int th = 0, nv = 0;
+            sscanf(e, "%d,%d", &th, &nv);
+#define LGV(TH, NV) if (th == TH && nv == NV && V <= TH * 4 * NV) { k_lsm_large<MODE, TH, NV><<<grid, TH, 0, stream>>>(x, out, labels, rows, V, T, U, blank, bw); return hipGetLastError(); }
+            LGV(256, 2) LGV(256, 4) LGV(256, 8) LGV(256, 16) LGV(512, 2) LGV(512, 4) LGV(512, 8) LGV(1024, 2) LGV(1024, 4)
+#undef LGV
+        }
+#endif
+        if (V <= 4096)
+            k_lsm_large<MODE, 256, 4><<<grid, 256, 0, stream>>>(x, out, labels, rows, V, T, U, blank, bw);
+        else if (V <= 8192)
+            k_lsm_large<MODE, 256, 8><<<grid, 256, 0, stream>>>(x, out, labels, rows, V, T, U, blank, bw);
+        else
+            k_lsm_large<MODE, 512, 8><<<grid, 512, 0, stream>>>(x, out, labels, rows, V, T, U, blank, bw);
     } else {
         k_lsm_generic<MODE><<<(unsigned)((rows + 3) / 4), 256, 0, stream>>>(x, out, labels, rows, V, T,
                                                                              U, blank, bw);
@@ -416,6 +435,7 @@ k_lsmbwd_small(const float* dy, const float* y, float* dx, int64_t rows, int V, 
     for (int e = (nvec << 2) + tid; e < nel; e += SM_THREADS) dst[e] = tdy[e];
 }
 
+template <int LG_THREADS, int LG_MAXVEC>
 __global__ void __launch_bounds__(LG_THREADS)
 k_lsmbwd_large(const float* dy, const float* y, float* dx, int64_t rows, int V) {
     __shared__ float red[LG_THREADS / WAVE];
@@ -430,7 +450,7 @@ k_lsmbwd_large(const float* dy, const float* y, float* dx, int64_t rows, int V) 
             const int j = threadIdx.x + i * LG_THREADS;
             if (j < nvec) { g[i] = sdy[j]; s += (g[i].x + g[i].y) + (g[i].z + g[i].w); }
         }
-        s = block_reduce(s, false, red);
+        s = block_reduce<LG_THREADS>(s, false, red);
         float4* dst = reinterpret_cast<float4*>(dx + row * V);
 #pragma unroll
         for (int i = 0; i < LG_MAXVEC; ++i) {
@@ -476,8 +496,11 @@ hipError_t launch_log_softmax_backward(hipStream_t stream, const float* dy, cons
 #define LSMB_SMALL(LL) case LL: k_lsmbwd_small<LL><<<grid, SM_THREADS, lds, stream>>>(dy, y, dx, rows, V, R, q); break;
         switch (L) { LSMB_SMALL(1) LSMB_SMALL(2) LSMB_SMALL(4) LSMB_SMALL(8) LSMB_SMALL(16) LSMB_SMALL(32) LSMB_SMALL(64) }
 #undef LSMB_SMALL
-    } else if (aligned && V % 4 == 0 && V <= LG_THREADS * 4 * LG_MAXVEC) {
-        k_lsmbwd_large<<<(unsigned)(rows < (1 << 22) ? rows : (1 << 22)), LG_THREADS, 0, stream>>>(dy, y, dx, rows, V);
+    } else if (aligned && V % 4 == 0 && V <= LG_MAXV) {
+        const unsigned grid = (unsigned)(rows < (1 << 22) ? rows : (1 << 22));
+        if (V <= 4096) k_lsmbwd_large<256, 4><<<grid, 256, 0, stream>>>(dy, y, dx, rows, V);
+        else if (V <= 8192) k_lsmbwd_large<256, 8><<<grid, 256, 0, stream>>>(dy, y, dx, rows, V);
+        else k_lsmbwd_large<512, 8><<<grid, 512, 0, stream>>>(dy, y, dx, rows, V);
     } else {
         k_lsmbwd_generic<<<(unsigned)((rows + 3) / 4), 256, 0, stream>>>(dy, y, dx, rows, V);
     }
