@@ -100,11 +100,14 @@ struct LsmBwd {
     const float* scale;  // (N,) upstream gradient per utterance, or nullptr
 };
 
-constexpr int SM_THREADS = 256;
+#ifndef RNNT_SM_THREADS
+#define RNNT_SM_THREADS 256
+#endif
+constexpr int SM_THREADS = RNNT_SM_THREADS;
 #ifndef RNNT_SM_FLOATS
 #define RNNT_SM_FLOATS 3200
 #endif
-constexpr int SM_FLOATS = RNNT_SM_FLOATS;   // LDS tile budget in floats (12.5 KiB; smaller tiles = more resident workgroups, measured best)
+constexpr int SM_FLOATS = RNNT_SM_FLOATS;   // LDS tile budget in floats: one pass of the 256 threads over a 12.5 KiB tile.  (512 threads x 25 KiB: 2 % faster in the isolated probe, slower in bench.py and in the fused gather mode; two passes per tile or 50 KiB tiles are clearly worse.)
 constexpr float LOG2E = 1.44269504088896340736f;
 constexpr float LN2 = 0.693147180559945309417f;
 
@@ -395,8 +398,10 @@ hipError_t launch_logits_backward(hipStream_t stream, const float* logits, const
 // Same three shapes as the forward kernels (LDS row tiles / one row per workgroup in
 // registers / wave per row); 12V bytes per row element (read dy, read y, write dx).
 // ---------------------------------------------------------------------------
+constexpr int SMB_THREADS = 256;   // backward: two tiles per workgroup, keep the 256-thread shape
+constexpr int SMB_FLOATS = 3200;
 template <int L>
-__global__ void __launch_bounds__(SM_THREADS)
+__global__ void __launch_bounds__(SMB_THREADS)
 k_lsmbwd_small(const float* dy, const float* y, float* dx, int64_t rows, int V, int R, int q) {
     extern __shared__ __attribute__((aligned(16))) float tile[];
     float* tdy = tile;
@@ -407,13 +412,13 @@ k_lsmbwd_small(const float* dy, const float* y, float* dx, int64_t rows, int V, 
     const int nel = nrows * V, nvec = nel >> 2;
     const float* sdy = dy + row0 * V;
     const float* sy = y + row0 * V;
-    for (int i = tid; i < nvec; i += SM_THREADS) {
+    for (int i = tid; i < nvec; i += SMB_THREADS) {
         reinterpret_cast<float4*>(tdy)[i] = reinterpret_cast<const float4*>(sdy)[i];
         reinterpret_cast<float4*>(ty)[i] = reinterpret_cast<const float4*>(sy)[i];
     }
-    for (int e = (nvec << 2) + tid; e < nel; e += SM_THREADS) { tdy[e] = sdy[e]; ty[e] = sy[e]; }
+    for (int e = (nvec << 2) + tid; e < nel; e += SMB_THREADS) { tdy[e] = sdy[e]; ty[e] = sy[e]; }
     __syncthreads();
-    constexpr int RPP = SM_THREADS / L;
+    constexpr int RPP = SMB_THREADS / L;
     const int h = tid % L, rr = tid / L;
     const int ctail = h + (q - 1) * L;
     const bool tail_ok = ctail < V;
@@ -430,9 +435,9 @@ k_lsmbwd_small(const float* dy, const float* y, float* dx, int64_t rows, int V, 
     }
     __syncthreads();
     float* dst = dx + row0 * V;
-    for (int i = tid; i < nvec; i += SM_THREADS)
+    for (int i = tid; i < nvec; i += SMB_THREADS)
         reinterpret_cast<float4*>(dst)[i] = reinterpret_cast<const float4*>(tdy)[i];
-    for (int e = (nvec << 2) + tid; e < nel; e += SM_THREADS) dst[e] = tdy[e];
+    for (int e = (nvec << 2) + tid; e < nel; e += SMB_THREADS) dst[e] = tdy[e];
 }
 
 template <int LG_THREADS, int LG_MAXVEC>
@@ -489,11 +494,11 @@ hipError_t launch_log_softmax_backward(hipStream_t stream, const float* dy, cons
         int L = 1;
         while (L < 64 && L * 16 < V) L <<= 1;
         const int q = (V + L - 1) / L;
-        int R = (SM_FLOATS / V) / 4 * 4;
+        int R = (SMB_FLOATS / V) / 4 * 4;
         if (R < 4) R = 4;
         const size_t lds = (size_t)R * V * sizeof(float) * 2;
         const unsigned grid = (unsigned)((rows + R - 1) / R);
-#define LSMB_SMALL(LL) case LL: k_lsmbwd_small<LL><<<grid, SM_THREADS, lds, stream>>>(dy, y, dx, rows, V, R, q); break;
+#define LSMB_SMALL(LL) case LL: k_lsmbwd_small<LL><<<grid, SMB_THREADS, lds, stream>>>(dy, y, dx, rows, V, R, q); break;
         switch (L) { LSMB_SMALL(1) LSMB_SMALL(2) LSMB_SMALL(4) LSMB_SMALL(8) LSMB_SMALL(16) LSMB_SMALL(32) LSMB_SMALL(64) }
 #undef LSMB_SMALL
     } else if (aligned && V % 4 == 0 && V <= LG_MAXV) {
