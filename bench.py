@@ -102,8 +102,18 @@ def cpu_baseline(cfg, utts):
         oracle.rnnt_loss_f32(lp1, ys1, xn1, yn1, blank=0, fastemit_lambda=lam, scan_mode=1)
     one_thread = len(xs1) / (time.perf_counter() - t1)
     oracle.set_threads(nthreads)
+    # BASELINE.json configs[0]: N=1, T=150, U=40, V=28 through the awni-style NumPy loops (ref_transduce.py
+    # itself is not available offline; oracle/transduce_np.py restates it), one host core
+    from oracle import transduce_np
+    rng = np.random.RandomState(1)
+    lp_c1 = transduce_np.log_softmax(rng.randn(1, 150, 40, 28))
+    ys_c1 = rng.randint(1, 28, (1, 39))
+    t2 = time.perf_counter()
+    transduce_np.transduce_batch(lp_c1, ys_c1, np.array([150]), np.array([39]), blank=0)
+    c1_ms = (time.perf_counter() - t2) * 1e3
     return {"value": round(utts_total / dt, 3), "unit": "utterances/s", "cores": nthreads,
             "kind": "port", "value_1_thread": round(one_thread, 3),
+            "awni_style_numpy_c1_ms": round(c1_ms, 2),
             "sample": f"{reps} passes over {utts} utterances of T={T},U={U},V={V} "
                       f"(log_softmax + gather + loss + grads), {dt:.2f} s wall, OpenMP over rows/utterances"}
 
