@@ -102,3 +102,29 @@ def test_compact_shape_errors():
         core.rnnt_loss_compact(xs, ys, xn, yn)
     with pytest.raises(RuntimeError, match="xs shape mismatch"):
         core.rnnt_loss_compact(xs, ys[:2].contiguous(), xn, yn)
+
+
+def test_compact_empty_utterance_is_contained():
+    """An utterance with xn = 0 owns no rows of the packing (the reference would index row -1,
+    core_compact.cu): its cost is NaN, every other utterance is unaffected, nothing is written
+    outside the other utterances' cells."""
+    import warp_rnnt._C as core
+    N, Tm, Um, V = 4, 21, 7, 6
+    logits, labels, xn, yn = make_case(5, N, Tm, Um, V, ragged=True)
+    lp = np_log_softmax32(logits)
+    ref = oracle.rnnt_loss_f32(lp, labels, xn, yn, blank=0, scan_mode=1)
+    keep = [0, 2, 3]
+    xn_bad = xn.copy()
+    xn_bad[1] = 0
+    V_ = lp.shape[-1]
+    xs = np.concatenate([lp[n, :xn[n], :yn[n] + 1].reshape(-1, V_) for n in keep])
+    ys = np.concatenate([labels[n, :yn[n]] for n in range(N)]).astype(np.int32)   # labels of n=1 stay packed
+    costs, grads, loc = core.rnnt_loss_compact(T(np.ascontiguousarray(xs)), T(ys), T(xn_bad), T(yn))
+    c = costs.cpu().numpy()
+    assert np.isnan(c[1])
+    np.testing.assert_allclose(c[keep], ref["costs"][keep], rtol=1e-5)
+    cumlen = torch.cumsum(T(xn_bad) * (T(yn) + 1), dim=0, dtype=torch.int32)
+    w = torch.ones(N, device=DEV)
+    dense = core.rnnt_loss_compact_backward(w, grads, cumlen, loc, V_, 0).cpu().numpy()
+    want = np.concatenate([ref["grads"][n, :xn[n], :yn[n] + 1].reshape(-1, V_) for n in keep])
+    np.testing.assert_allclose(dense, want, atol=1e-5)

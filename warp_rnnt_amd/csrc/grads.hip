@@ -22,6 +22,13 @@ template <int LOADER, int WRITER, bool COMPACT>
 __global__ void __launch_bounds__(256) k_grads(const GradArgs a) {
     const int n = blockIdx.y;
     const UttLens len = utt_lens<COMPACT>(a.xn, a.yn, n, a.T, a.U);
+    if (COMPACT && !len.ok) {          // packed layout: the utterance owns no cells, only its cost is reported
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            a.costs[n] = __builtin_nanf("");
+            if (a.mismatch) a.mismatch[n] = 1;
+        }
+        return;
+    }
     const int Tn = len.Tn, Un = len.Un;
     const int T = COMPACT ? Tn : a.T, U = COMPACT ? Un : a.U;     // compact: per-utterance planes
     const size_t nb = COMPACT ? (size_t)a.offs[n] : (size_t)n * T * U;

@@ -215,6 +215,7 @@ template <int LOADER, bool BETA, bool COMPACT>
 __device__ __forceinline__ void sweep(const LatticeArgs& a, const int n, float (*mail)[RING],
                                       float (*trash)[MAIL_TRASH]) {
     const UttLens len = utt_lens<COMPACT>(a.xn, a.yn, n, a.T, a.U);
+    if (COMPACT && !len.ok) return;   // no plane of its own to sweep (uniform over the workgroup, before any barrier)
     const int Tn = len.Tn, Un = len.Un;
     // padded planes (N,T,U), or -- compact layout -- one (T_n,U_n) plane per utterance at offs[n]
     const int T = COMPACT ? Tn : a.T, U = COMPACT ? Un : a.U;

@@ -157,6 +157,7 @@ __device__ __forceinline__ void compute_block(const f32x2 (&cur)[K], const float
 template <bool BETA, bool COMPACT>
 __device__ __forceinline__ void sweep(const LatticeArgs& a, const int n, Smem* smem) {
     const UttLens len = utt_lens<COMPACT>(a.xn, a.yn, n, a.T, a.U);
+    if (COMPACT && !len.ok) return;   // no plane of its own to sweep (uniform over the workgroup, before any barrier)
     const int Tn = len.Tn, Un = len.Un;
     const int T = COMPACT ? Tn : a.T, U = COMPACT ? Un : a.U;
     const int lane = threadIdx.x & (WAVE - 1);
