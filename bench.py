@@ -135,6 +135,8 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
 
+    from warp_rnnt_amd import _build
+    _build.ensure_built()              # no-op when the prebuilt library travelled with the tree
     import warp_rnnt
     from warp_rnnt_amd import ops
 

@@ -59,5 +59,22 @@ def build(force=False, verbose=False, extra_flags=()):
     return LIB
 
 
+def ensure_built():
+    """Build the library if it is missing, safely when several ranks of one node start together
+    (exclusive file lock; the others find it built).  This is what bench.py and smoke() call; the
+    package itself never builds on import and fails loudly without the library (_lib.load)."""
+    if os.path.exists(LIB):
+        return LIB
+    import fcntl
+    with open(os.path.join(HERE, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not os.path.exists(LIB):
+                build()
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+    return LIB
+
+
 if __name__ == "__main__":
     print(build(verbose=True))
