@@ -128,6 +128,12 @@ rnntStatus_t rnnt_amd_expand_grads(rnntStream_t stream, const float *grads_diago
  *   loc (STU,) int64 vocabulary index of the label channel per row (NULL = not wanted).
  */
 size_t rnnt_amd_workspace_size_compact(int N, int64_t STU);
+/* One launch for what binding.cpp:139-170 does with a chain of tensor ops: cell_offsets (N+1,) int64 and
+ * label_offsets (N+1,) int32 exclusive prefix sums of xn*(yn+1) and yn, and
+ * stats[4] (device, int64) = {sum of cells (= STU), sum of yn, max xn, max yn} -- the caller reads
+ * stats back once to size the launches.  N <= 65535. */
+rnntStatus_t rnnt_amd_compact_offsets(rnntStream_t stream, const int *xn, const int *yn, int N,
+                                      int64_t *cell_offsets, int *label_offsets, int64_t *stats);
 rnntStatus_t rnnt_amd_loss_compact(rnntStream_t stream, void *workspace, const float *xs, const int *ys,
                                    const int *xn, const int *yn, const int64_t *cell_offsets,
                                    const int *label_offsets, float *costs, float *grads2, int64_t *loc,

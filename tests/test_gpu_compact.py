@@ -128,3 +128,24 @@ def test_compact_empty_utterance_is_contained():
     dense = core.rnnt_loss_compact_backward(w, grads, cumlen, loc, V_, 0).cpu().numpy()
     want = np.concatenate([ref["grads"][n, :xn[n], :yn[n] + 1].reshape(-1, V_) for n in keep])
     np.testing.assert_allclose(dense, want, atol=1e-5)
+
+
+@pytest.mark.parametrize("N", [1, 7, 1024, 1025, 40000])
+def test_compact_offsets_kernel(N):
+    """rnnt_amd_compact_offsets: prefix sums + maxima in one launch."""
+    import warp_rnnt_amd
+    L = warp_rnnt_amd.load()
+    rng = np.random.RandomState(N)
+    xn = rng.randint(1, 3000, (N,)).astype(np.int32)
+    yn = rng.randint(0, 700, (N,)).astype(np.int32)
+    offs = torch.empty((N + 1,), dtype=torch.int64, device=DEV)
+    loffs = torch.empty((N + 1,), dtype=torch.int32, device=DEV)
+    stats = torch.empty((4,), dtype=torch.int64, device=DEV)
+    txn, tyn = T(xn), T(yn)      # keep the device copies alive across the call
+    st = L.rnnt_amd_compact_offsets(torch.cuda.current_stream().cuda_stream, txn.data_ptr(), tyn.data_ptr(), N,
+                                    offs.data_ptr(), loffs.data_ptr(), stats.data_ptr())
+    assert st == 0
+    cells = xn.astype(np.int64) * (yn.astype(np.int64) + 1)
+    np.testing.assert_array_equal(offs.cpu().numpy(), np.concatenate([[0], np.cumsum(cells)]))
+    np.testing.assert_array_equal(loffs.cpu().numpy(), np.concatenate([[0], np.cumsum(yn)]).astype(np.int32))
+    assert stats.tolist() == [int(cells.sum()), int(yn.sum()), int(xn.max()), int(yn.max())]

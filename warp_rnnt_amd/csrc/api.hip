@@ -158,6 +158,16 @@ size_t rnnt_amd_workspace_size_compact(int N, int64_t STU) {
     return align_up((size_t)STU * 4) * 2 + align_up((size_t)STU * 8) + align_up((size_t)N * 4) * 2 + ALIGN;
 }
 
+// Device-side preparation of a compact batch (offsets + launch bounds), one launch.
+rnntStatus_t rnnt_amd_compact_offsets(rnntStream_t stream, const int* xn, const int* yn, int N,
+                                      int64_t* cell_offsets, int* label_offsets, int64_t* stats) {
+    if (N < 0 || N > 65535 || !cell_offsets || !label_offsets || !stats) return RNNT_STATUS_INVALID_ARGUMENT;
+    if (N > 0 && (!xn || !yn)) return RNNT_STATUS_INVALID_ARGUMENT;
+    if (launch_compact_offsets(stream, xn, yn, N, cell_offsets, label_offsets, stats) != hipSuccess)
+        return RNNT_STATUS_PROLOGUE_FAILED;
+    return RNNT_STATUS_SUCCESS;
+}
+
 // Compact (ragged packed) layout: replaces run_gather_for_compact + run_warp_rnnt_compact
 // (core.h:41-54, core_compact.cu:360-436) with the conventions of the rest of this ABI
 // (status codes, caller's stream, no exit(), no host synchronisation).

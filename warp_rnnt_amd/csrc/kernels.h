@@ -47,6 +47,8 @@ hipError_t launch_gather(hipStream_t stream, const float* log_probs, const int* 
                          int N, int T, int U, int V, int blank, bool skewed);
 hipError_t launch_reskew(hipStream_t stream, const float* lp2_rowmajor, float* ws2, int N, int T, int U);
 // compact (ragged packed) layout, core_compact.cu:403-436,456-484
+hipError_t launch_compact_offsets(hipStream_t stream, const int* xn, const int* yn, int N, int64_t* cell_offs,
+                                  int* label_offs, int64_t* stats);
 hipError_t launch_gather_compact(hipStream_t stream, const float* xs, const int* ys, const int* xn,
                                  const int* yn, const int64_t* offs, const int* label_offs, float* ws2,
                                  int64_t* loc, int N, int Tmax, int Umax, int V, int blank);

@@ -11,6 +11,7 @@
 //
 // Output of the gather kernels is the diagonal-major float2 workspace
 // (common.h) that the lattice sweep reads with coalesced row loads.
+#include <climits>
 #include <cstdio>
 #include <cstdlib>
 #include "common.h"
@@ -677,6 +678,73 @@ hipError_t launch_gather_compact(hipStream_t stream, const float* xs, const int*
     k_gather_compact<<<(unsigned)nblk, 256, 0, stream>>>(xs, ys, xn, yn, offs, label_offs,
                                                          reinterpret_cast<float2*>(ws2), loc, V, blank,
                                                          tiles_t, tiles_u);
+    return hipGetLastError();
+}
+
+// Prefix sums and launch bounds of a compact batch in ONE launch (the reference's binding does this
+// with a chain of torch ops and four host synchronisations, binding.cpp:139-170):
+//   cell_offsets[0..N] = exclusive sums of xn*(yn+1) (int64), label_offsets[0..N] = exclusive sums of yn,
+//   stats = {sum cells, sum labels, max xn, max yn}.  One workgroup; N <= 65535.
+constexpr int CP_THREADS = 1024;
+__global__ void __launch_bounds__(CP_THREADS)
+k_compact_offsets(const int* __restrict__ xn, const int* __restrict__ yn, int N, int64_t* __restrict__ cell_offs,
+                  int* __restrict__ label_offs, int64_t* __restrict__ stats) {
+    __shared__ int64_t s_cells[CP_THREADS];
+    __shared__ int s_labs[CP_THREADS];
+    __shared__ int s_tmax[CP_THREADS / WAVE], s_umax[CP_THREADS / WAVE];
+    const int tid = threadIdx.x;
+    const int per = (N + CP_THREADS - 1) / CP_THREADS;
+    const int lo = min(tid * per, N), hi = min(lo + per, N);
+    int64_t c = 0;
+    int l = 0, tmax = INT_MIN, umax = INT_MIN;
+    for (int n = lo; n < hi; ++n) {
+        const int x = xn[n], y = yn[n];
+        c += (int64_t)x * (y + 1);
+        l += y;
+        tmax = max(tmax, x);
+        umax = max(umax, y);
+    }
+    s_cells[tid] = c;
+    s_labs[tid] = l;
+    for (int o = 32; o > 0; o >>= 1) {
+        tmax = max(tmax, __shfl_xor(tmax, o));
+        umax = max(umax, __shfl_xor(umax, o));
+    }
+    if ((tid & (WAVE - 1)) == 0) { s_tmax[tid >> 6] = tmax; s_umax[tid >> 6] = umax; }
+    __syncthreads();
+    // Hillis-Steele inclusive scan over the 1024 per-thread totals
+    for (int o = 1; o < CP_THREADS; o <<= 1) {
+        int64_t vc = 0;
+        int vl = 0;
+        if (tid >= o) { vc = s_cells[tid - o]; vl = s_labs[tid - o]; }
+        __syncthreads();
+        s_cells[tid] += vc;
+        s_labs[tid] += vl;
+        __syncthreads();
+    }
+    int64_t cbase = s_cells[tid] - c;     // exclusive
+    int lbase = s_labs[tid] - l;
+    for (int n = lo; n < hi; ++n) {
+        cell_offs[n] = cbase;
+        label_offs[n] = lbase;
+        cbase += (int64_t)xn[n] * (yn[n] + 1);
+        lbase += yn[n];
+    }
+    if (tid == CP_THREADS - 1) {
+        cell_offs[N] = s_cells[tid];
+        label_offs[N] = s_labs[tid];
+        int tm = s_tmax[0], um = s_umax[0];
+        for (int i = 1; i < CP_THREADS / WAVE; ++i) { tm = max(tm, s_tmax[i]); um = max(um, s_umax[i]); }
+        stats[0] = s_cells[tid];
+        stats[1] = s_labs[tid];
+        stats[2] = tm;
+        stats[3] = um;
+    }
+}
+
+hipError_t launch_compact_offsets(hipStream_t stream, const int* xn, const int* yn, int N, int64_t* cell_offs,
+                                  int* label_offs, int64_t* stats) {
+    k_compact_offsets<<<1, CP_THREADS, 0, stream>>>(xn, yn, N, cell_offs, label_offs, stats);
     return hipGetLastError();
 }
 

@@ -103,13 +103,11 @@ def loss_compact(xs, ys, xn, yn, blank=0, fastemit_lambda=0.0, required_grad=Tru
         grads = torch.empty((STU, 2), dtype=torch.float32, device=dev) if required_grad else None
         if N == 0:
             return costs, grads, loc
-        cells = xn.to(torch.int64) * (yn.to(torch.int64) + 1)
-        offs = torch.zeros((N + 1,), dtype=torch.int64, device=dev)
-        torch.cumsum(cells, 0, out=offs[1:])
-        loffs = torch.zeros((N + 1,), dtype=torch.int32, device=dev)
-        torch.cumsum(yn, 0, out=loffs[1:])
-        stats = torch.stack([offs[-1], loffs[-1].to(torch.int64), xn.max().to(torch.int64),
-                             yn.max().to(torch.int64)]).tolist()          # the one host sync
+        offs = torch.empty((N + 1 + 4,), dtype=torch.int64, device=dev)    # offsets + the 4 stats
+        loffs = torch.empty((N + 1,), dtype=torch.int32, device=dev)
+        _check(L.rnnt_amd_compact_offsets(_stream(dev), xn.data_ptr(), yn.data_ptr(), N, offs.data_ptr(),
+                                          loffs.data_ptr(), offs[N + 1:].data_ptr()))
+        stats = offs[N + 1:].tolist()                                       # the one host sync
         stu_chk, su, tmax, umax = int(stats[0]), int(stats[1]), int(stats[2]), int(stats[3]) + 1
         if ys.numel() != su:
             raise RuntimeError("ys shape must be equal to (sum(yn), )")
