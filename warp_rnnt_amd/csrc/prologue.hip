@@ -527,25 +527,30 @@ constexpr int TD = 32;   // tile edge
 #define RNNT_GATHER_REVERSE 0
 #endif
 
+#ifndef RNNT_GATHER_TT
+#define RNNT_GATHER_TT 32
+#endif
+constexpr int TT = RNNT_GATHER_TT;   // frames per tile of k_to_diagonal (columns: TD)
+
 template <bool DENSE>
 __global__ void __launch_bounds__(256)
 k_to_diagonal(const float* __restrict__ src, const int* __restrict__ labels, float2* __restrict__ ws2,
               int T, int U, int V, int blank, int tiles_t, int tiles_u) {
-    __shared__ float2 tile[TD][TD];
+    __shared__ float2 tile[TT][TD];
     // (probe knob: walking the tensor back to front to catch the producer's tail in L2/MALL
     //  measured no gain at 1.44 GB)
     unsigned b = RNNT_GATHER_REVERSE ? gridDim.x - 1 - blockIdx.x : blockIdx.x;
     const int tu = b % tiles_u; b /= tiles_u;
     const int tt = b % tiles_t;
     const int n = b / tiles_t;
-    const int t0 = tt * TD, u0 = tu * TD;
+    const int t0 = tt * TT, u0 = tu * TD;
     const int ul = threadIdx.x & (TD - 1), tl0 = threadIdx.x >> 5;   // 8 rows of 32 lanes
     const int u = u0 + ul;
     const size_t nbase = (size_t)n * T * U;
     int lab = blank;
     if (DENSE && u < U - 1) lab = labels[(size_t)n * (U - 1) + u];
 #pragma unroll
-    for (int k = 0; k < TD / 8; ++k) {
+    for (int k = 0; k < TT / 8; ++k) {
         const int tl = tl0 + 8 * k, t = t0 + tl;
         if (t < T && u < U) {
             const size_t cell = nbase + (size_t)t * U + u;
@@ -561,10 +566,10 @@ k_to_diagonal(const float* __restrict__ src, const int* __restrict__ labels, flo
     // diagonal d of the tile holds cells (tl = d - ul, ul): consecutive ul = consecutive pairs of
     // row (t0+u0+d) mod T of the diagonal-major plane
 #pragma unroll
-    for (int k = 0; k < (2 * TD) / 8; ++k) {
+    for (int k = 0; k < (TT + TD + 7) / 8; ++k) {
         const int d = tl0 + 8 * k;
         const int tl = d - ul;
-        if (d < 2 * TD - 1 && tl >= 0 && tl < TD) {
+        if (d < TT + TD - 1 && tl >= 0 && tl < TT) {
             const int t = t0 + tl;
             if (t < T && u < U) {
                 int r = t + u;
@@ -589,7 +594,7 @@ k_gather_rowmajor(const float* __restrict__ lp, const int* __restrict__ labels, 
 static hipError_t launch_to_diagonal(hipStream_t stream, const float* src, const int* labels, float* ws2,
                                      int N, int T, int U, int V, int blank, bool dense) {
     if ((size_t)N * T * U == 0) return hipSuccess;
-    const int tiles_t = (T + TD - 1) / TD, tiles_u = (U + TD - 1) / TD;
+    const int tiles_t = (T + TT - 1) / TT, tiles_u = (U + TD - 1) / TD;
     const size_t nblk = (size_t)N * tiles_t * tiles_u;
     if (nblk >= ((size_t)1 << 31)) return hipErrorInvalidValue;
     if (dense)
