@@ -15,6 +15,8 @@ rocprofv3 --kernel-trace --stats -d $OUT/stats_c3 -o c3 -- python $R/bench.py --
 rocprofv3 --kernel-trace --stats -d $OUT/stats_c2 -o c2 -- python $R/bench.py --config c2 --steps 50 --warmup 3 --no-cpu-baseline > /dev/null 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -o c4 -- python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -o c4 -- python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline > /dev/null 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch_c3 -o c3 -- python $R/bench.py --config c3 --steps 10 --warmup 2 --no-cpu-baseline > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write_c3 -o c3 -- python $R/bench.py --config c3 --steps 10 --warmup 2 --no-cpu-baseline > /dev/null 2>&1
 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU --kernel-trace --output-format csv -d $OUT/pmc_sq1 -o c4 -- python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline > /dev/null 2>&1
 rocprofv3 --pmc SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_SCA --kernel-trace --output-format csv -d $OUT/pmc_sq2 -o c4 -- python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline > /dev/null 2>&1
 for l in warp-rnnt warp-rnnt-gather warp-rnnt-compact warp-rnnt-fused; do
