@@ -112,7 +112,17 @@ constexpr int SM_FLOATS = RNNT_SM_FLOATS;   // LDS tile budget in floats: one pa
 constexpr float LOG2E = 1.44269504088896340736f;
 constexpr float LN2 = 0.693147180559945309417f;
 
-template <int L, int MODE>
+// WP ("wave private", L <= 16 and one pass per tile): every wave stages, normalises and stores its own
+// WAVE/L consecutive rows (a multiple of 4, so its chunk is 16-byte aligned) and the workgroup never
+// synchronises -- 32 independent streams per CU instead of 8 workgroups that each wait for their slowest wave.
+__device__ __forceinline__ void wave_sync_lds() {
+    // LDS operations of one wave retire in order; this only stops the compiler from moving them
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <int L, int MODE, bool WP>
 __global__ void __launch_bounds__(SM_THREADS)
 k_lsm_small(const float* x, float* out, const int* __restrict__ labels,
             int64_t rows, int V, int R, int q, int T, int U, int blank, LsmBwd bw) {
@@ -124,13 +134,28 @@ k_lsm_small(const float* x, float* out, const int* __restrict__ labels,
     const int nrows = (int)min((int64_t)R, rows - row0);
     const int nel = nrows * V;                      // floats in this chunk
     const float* src = x + row0 * V;                // 16-byte aligned: R % 4 == 0 (out may alias x)
+    // wave-private view of the same tile: rows [wr0, wr0 + wn) of the chunk
+    constexpr int RW = (WAVE / L) > 0 ? (WAVE / L) : 1;
+    const int lane = tid & (WAVE - 1);
+    const int wr0 = (tid >> 6) * RW;
+    const int wn = min(max(nrows - wr0, 0), RW);
+    const int wel = wn * V, wvec = wel >> 2;
+    float* wtile = tile + wr0 * V;
 
     // ---- stage: the tile is a plain copy of the chunk ----
     const int nvec = nel >> 2;
-    for (int i = tid; i < nvec; i += SM_THREADS)
-        reinterpret_cast<float4*>(tile)[i] = RNNT_LSM_LOAD(reinterpret_cast<const float4*>(src) + i);
-    for (int e = (nvec << 2) + tid; e < nel; e += SM_THREADS) tile[e] = src[e];   // last chunk only
-    __syncthreads();
+    if constexpr (WP) {
+        const float* wsrc = src + (size_t)wr0 * V;
+        for (int i = lane; i < wvec; i += WAVE)
+            reinterpret_cast<float4*>(wtile)[i] = RNNT_LSM_LOAD(reinterpret_cast<const float4*>(wsrc) + i);
+        for (int e = (wvec << 2) + lane; e < wel; e += WAVE) wtile[e] = wsrc[e];
+        wave_sync_lds();
+    } else {
+        for (int i = tid; i < nvec; i += SM_THREADS)
+            reinterpret_cast<float4*>(tile)[i] = RNNT_LSM_LOAD(reinterpret_cast<const float4*>(src) + i);
+        for (int e = (nvec << 2) + tid; e < nel; e += SM_THREADS) tile[e] = src[e];   // last chunk only
+        __syncthreads();
+    }
 
     // ---- per-row max / sum(exp) / normalise: L lanes per row, lane h owns columns h, h+L, ... ----
     constexpr int RPP = SM_THREADS / L;             // rows per pass
@@ -167,7 +192,16 @@ k_lsm_small(const float* x, float* out, const int* __restrict__ labels,
             if (tail_ok) row[ctail] = (row[ctail] - mx) - ls;
         }
     }
-    if constexpr (GATHER) {
+    if constexpr (GATHER && WP) {
+        wave_sync_lds();
+        for (int r = wr0 + lane; r < wr0 + wn; r += WAVE) {
+            const CellMap m = map_cell((size_t)(row0 + r), labels, T, U, blank);
+            const float2 st = stat[r];
+            const float* row = tile + r * V;
+            reinterpret_cast<float2*>(out)[m.sk] =
+                make_float2((row[blank] - st.x) - st.y, (row[m.label] - st.x) - st.y);
+        }
+    } else if constexpr (GATHER) {
         // one lane per row with all lanes busy (the per-row index arithmetic costs ~60 instructions;
         // doing it inside the L-lane row loop ran it with a quarter of the lanes)
         __syncthreads();
@@ -178,6 +212,12 @@ k_lsm_small(const float* x, float* out, const int* __restrict__ labels,
             reinterpret_cast<float2*>(out)[m.sk] =
                 make_float2((row[blank] - st.x) - st.y, (row[m.label] - st.x) - st.y);
         }
+    } else if constexpr (WP) {
+        wave_sync_lds();
+        float* wdst = out + (row0 + wr0) * V;
+        for (int i = lane; i < wvec; i += WAVE)
+            RNNT_LSM_STORE(reinterpret_cast<float4*>(wdst) + i, reinterpret_cast<const float4*>(wtile)[i]);
+        for (int e = (wvec << 2) + lane; e < wel; e += WAVE) wdst[e] = wtile[e];
     } else {
         __syncthreads();
         float* dst = out + row0 * V;
@@ -341,12 +381,23 @@ static hipError_t dispatch_lsm(hipStream_t stream, const float* x, float* out, c
         const int rpp = SM_THREADS / L;                // rows per pass, a multiple of 4
         int R = (SM_FLOATS / V) / rpp * rpp;           // whole passes
         if (R < rpp) R = rpp;
+        // wave-private tiles: each wave owns WAVE/L rows (a multiple of 4 for L <= 16), one pass
+        static const bool no_wp = getenv("RNNT_LSM_NO_WP") != nullptr;
+        // Plain log-softmax only: measured 2-3 % faster there (0.506 -> 0.493 ms at c4), slower for the fused
+        // gather (its one-lane-per-row mapping phase wants all rows of the tile in ONE wave: 0.52 -> 0.556 ms)
+        // and for the fused backward (+15 us).
+        const bool wp = (L <= 16) && !no_wp && MODE == LSM_NORM;
+        if (wp) R = rpp;
         const size_t lds = (size_t)R * V * sizeof(float) + (GATHER ? (size_t)R * sizeof(float2) : 0);
         const unsigned grid = (unsigned)((rows + R - 1) / R);
 #define LSM_SMALL(LL)                                                                           \
     case LL:                                                                                    \
-        k_lsm_small<LL, MODE><<<grid, SM_THREADS, lds, stream>>>(x, out, labels, rows, V, R, q, T, U,  \
-                                                                  blank, bw);                   \
+        if (wp && LL <= 16)                                                                     \
+            k_lsm_small<LL, MODE, (LL <= 16)><<<grid, SM_THREADS, lds, stream>>>(x, out, labels, rows, V, R, q, \
+                                                                                 T, U, blank, bw);             \
+        else                                                                                    \
+            k_lsm_small<LL, MODE, false><<<grid, SM_THREADS, lds, stream>>>(x, out, labels, rows, V, R, q, T,   \
+                                                                            U, blank, bw);                     \
         break;
         switch (L) {
             LSM_SMALL(1) LSM_SMALL(2) LSM_SMALL(4) LSM_SMALL(8) LSM_SMALL(16) LSM_SMALL(32)
