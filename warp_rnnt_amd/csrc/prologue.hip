@@ -411,7 +411,7 @@ static hipError_t dispatch_lsm(hipStream_t stream, const float* x, float* out, c
             int th = 0, nv = 0;
             sscanf(e, "%d,%d", &th, &nv);
 #define LGV(TH, NV) if (th == TH && nv == NV && V <= TH * 4 * NV) { k_lsm_large<MODE, TH, NV><<<grid, TH, 0, stream>>>(x, out, labels, rows, V, T, U, blank, bw); return hipGetLastError(); }
-            LGV(256, 2) LGV(256, 4) LGV(256, 8) LGV(256, 16) LGV(512, 2) LGV(512, 4) LGV(512, 8) LGV(1024, 2) LGV(1024, 4)
+            LGV(64, 20) LGV(64, 40) LGV(128, 10) LGV(128, 20) LGV(256, 2) LGV(256, 4) LGV(256, 8) LGV(256, 16) LGV(512, 2) LGV(512, 4) LGV(512, 8) LGV(1024, 2) LGV(1024, 4)
 #undef LGV
         }
 #endif
