@@ -377,6 +377,9 @@ static hipError_t dispatch_lsm(hipStream_t stream, const float* x, float* out, c
     if (aligned && V <= 1024) {
         int L = 1;
         while (L < 64 && L * 16 < V) L <<= 1;          // <= 16 columns per lane
+#ifdef RNNT_LG_PROBE
+        if (const char* e = getenv("RNNT_LSM_L")) { const int l = atoi(e); if (l >= 1 && l <= 64 && (l & (l - 1)) == 0) L = l; }
+#endif
         const int q = (V + L - 1) / L;
         const int rpp = SM_THREADS / L;                // rows per pass, a multiple of 4
         int R = (SM_FLOATS / V) / rpp * rpp;           // whole passes
