@@ -9,6 +9,7 @@ import torch
 from warp_rnnt_amd import _lib
 path = sys.argv[1]
 N, T, U, V = (int(v) for v in sys.argv[2:6]) if len(sys.argv) > 5 else (16, 1500, 300, 50)
+KIND = int(os.environ.get("PROBE_INPUT_KIND", "0"))      # 0 dense log-probs, 2 logits (fused log-softmax + gather)
 L = ctypes.CDLL(path)
 for sym, (res, a_) in _lib.SYMBOLS.items():
     if hasattr(L, sym):
@@ -25,7 +26,7 @@ for r in range(14):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(5):
-        st = L.rnnt_amd_loss(s, ws.data_ptr(), 0, lp.data_ptr(), ys.data_ptr(), xn.data_ptr(), yn.data_ptr(),
+        st = L.rnnt_amd_loss(s, ws.data_ptr(), KIND, lp.data_ptr(), ys.data_ptr(), xn.data_ptr(), yn.data_ptr(),
                              costs.data_ptr(), grads.data_ptr(), 1, N, T, U, V, 0, 0.0)
     e1.record(); torch.cuda.synchronize()
     assert st == 0
