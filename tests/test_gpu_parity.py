@@ -387,3 +387,36 @@ def test_out_of_range_lengths_are_contained(gather, U):
     c = c.cpu().numpy()
     assert np.isnan(c[[0, 2, 3]]).all()
     np.testing.assert_allclose(c[[1, 4]], ref["costs"][[1, 4]], rtol=1e-5)
+
+
+@pytest.mark.parametrize("gather", [False, True])
+def test_long_utterance_without_labels_accuracy(gather):
+    """U_n == 1 (empty transcript), T_n ~ 1000, sharp logits: alpha/beta are pure prefix/suffix sums.  Serial fp32
+    accumulation drifts by ~0.3*sqrt(T) ulp per direction (6e-3 on the gradients here); the reference scans its
+    boundary chains (core_gather.cu:86-104,187-205) and so does single_column_scan: the HIP path must stay as
+    close to exact arithmetic as the fp32 oracle does."""
+    from oracle import transduce_np
+    N, T, U, V = 3, 1174, 9, 10
+    rng = np.random.RandomState(4)
+    logits = (rng.randn(N, T, U, V) * 4.0).astype(np.float32)
+    labels = rng.randint(1, V, (N, U - 1)).astype(np.int32)
+    xn = np.array([970, 1174, 1], dtype=np.int32)
+    yn = np.array([0, 0, 0], dtype=np.int32)
+    lp = np_log_softmax32(logits)
+    ref = oracle.rnnt_loss_f32(lp, labels, xn, yn, blank=0, scan_mode=1)
+    c64, g64 = transduce_np.transduce_batch(lp.astype(np.float64), labels, xn, yn, blank=0, fast=True)
+    if gather:
+        lp2 = oracle.gather_f32(lp, labels, 0)
+        c, g = run_native(lp2, labels, xn, yn, blank=-1)
+        idx = np.concatenate([labels, np.zeros((N, 1), np.int32)], 1).astype(np.int64)     # (N,U) label per column
+        lab64 = np.take_along_axis(g64, idx[:, None, :, None].repeat(T, 1), axis=3)[..., 0]
+        lab64[:, :, U - 1] = 0.0                                                            # no label on the last column
+        g64 = np.stack([g64[..., 0], lab64], -1)
+        gref = oracle.rnnt_loss_f32(lp2, labels, xn, yn, blank=-1, scan_mode=1)["grads"]
+    else:
+        c, g = run_native(lp, labels, xn, yn, blank=0)
+        gref = ref["grads"]
+    np.testing.assert_allclose(c, c64, rtol=2e-6)
+    err_hip, err_ora = np.abs(g - g64).max(), np.abs(gref - g64).max()
+    print(f"U_n=1, T_n={xn.tolist()}: max |grad - fp64|: hip {err_hip:.2e}, fp32 oracle {err_ora:.2e}")
+    assert err_hip <= 3.0 * err_ora + 1e-5

@@ -22,11 +22,14 @@ import oracle  # noqa: E402  (checker only)
 from helpers import np_log_softmax32  # noqa: E402
 
 COST_RTOL, COST_ATOL, GRAD_ATOL = 2e-5, 2e-5, 1e-4
+BIG_FRACTION = 0.0
 
 
 def draw_case(rng):
     kind = rng.randint(10)
-    if kind < 5:
+    if rng.rand() < BIG_FRACTION:   # BASELINE-size lattices (five column blocks, ~1800 diagonals), ragged
+        N, T, U, V = rng.randint(1, 4), rng.randint(900, 1501), rng.randint(200, 301), rng.randint(2, 12)
+    elif kind < 5:
         N, T, U, V = rng.randint(1, 10), rng.randint(1, 120), rng.randint(1, 90), rng.randint(2, 40)
     elif kind < 7:      # multi column-block / ws-kernel limit
         N, T, U, V = rng.randint(1, 4), rng.randint(1, 300), rng.randint(60, 530), rng.randint(2, 9)
@@ -87,7 +90,10 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=60.0)
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--big", type=float, default=0.0, help="fraction of BASELINE-size lattices (T<=1500, U<=300)")
     args = ap.parse_args()
+    global BIG_FRACTION
+    BIG_FRACTION = args.big
     import warp_rnnt
     import warp_rnnt._C as core
     from warp_rnnt_amd.fused import rnnt_loss_from_logits

@@ -51,6 +51,36 @@ __device__ __forceinline__ UttLens utt_lens(const int* xn, const int* yn, int n,
     return l;
 }
 
+// Single-column lattice (U_n == 1, an utterance without labels): alpha[t,0] / beta[t,0] are plain prefix /
+// suffix sums of the blank log-probs.  The general sweep would accumulate them serially -- T_n dependent
+// fp32 additions, a random walk of ~0.3*sqrt(T_n) ulp that the two directions do not share, which shows up
+// one to one in exp(alpha + beta - loglik) (6e-3 at T_n = 970, |loglik| = 2270).  The reference computes these
+// boundary chains with 32-wide shuffle scans plus a per-tile carry (core_gather.cu:86-104, 187-205); this does
+// the same with one wave: 64-wide inclusive scan per chunk, serial carry across chunks.
+// lpB(t) returns the blank log-prob of cell (t,0); out[t * pitch] receives the value.  Returns the total.
+template <bool BETA, typename F>
+__device__ __forceinline__ float single_column_scan(const int Tn, float* __restrict__ out, const int pitch,
+                                                    const int lane, F lpB) {
+    float carry = 0.0f;
+    for (int c0 = 0; c0 < Tn; c0 += WAVE) {
+        const int k = c0 + lane;                          // position in sweep order
+        const int t = BETA ? (Tn - 1 - k) : k;
+        const float v = k < Tn ? lpB(t) : 0.0f;
+        float s = v;
+#pragma unroll
+        for (int o = 1; o < WAVE; o <<= 1) {
+            const float y = __shfl_up(s, o, WAVE);
+            if (lane >= o) s += y;
+        }
+        // alpha[t,0] excludes the own cell (sum over frames before t); beta[t,0] includes it
+        float ex = __shfl_up(s, 1, WAVE);                 // exclusive prefix (exact, no s - v cancellation)
+        if (lane == 0) ex = 0.0f;
+        if (k < Tn) out[(size_t)t * pitch] = carry + (BETA ? s : ex);
+        carry += readlane(s, WAVE - 1);
+    }
+    return carry;
+}
+
 // How a kernel finds the blank / label log-probability of lattice cell (t,u).
 enum Loader : int {
     LOAD_SKEWED = 0,   // float2 workspace, diagonal-major (internal layout)

@@ -224,6 +224,18 @@ __device__ __forceinline__ void sweep(const LatticeArgs& a, const int n, float (
     const int nw = blockDim.x >> 6;
     const size_t nbase = COMPACT ? (size_t)a.offs[n] : (size_t)n * T * U;
     float* out = (BETA ? a.betas : a.alphas) + nbase;
+    if (Un == 1) {   // no labels: prefix / suffix sums by one wave (see common.h); uniform, before any barrier
+        if (w == 0) {
+            const float total = single_column_scan<BETA>(Tn, out, U, lane, [&](int t) {
+                if constexpr (LOADER == LOAD_DENSE)
+                    return a.lp[(nbase + (size_t)t * U) * (size_t)a.V + a.blank];
+                else   // diagonal-major and row-major pairs keep cell (t,0) at the same index t*U
+                    return reinterpret_cast<const float2*>(a.lp)[nbase + (size_t)t * U].x;
+            });
+            if (!BETA && lane == 0) a.ll[n] = total;
+        }
+        return;
+    }
     const int ndiag = Tn + Un - 1;
     const float NEG_INF = -__builtin_inff();
     constexpr int NB = ring_depth<LOADER>();

@@ -162,6 +162,16 @@ __device__ __forceinline__ void sweep(const LatticeArgs& a, const int n, Smem* s
     const int T = COMPACT ? Tn : a.T, U = COMPACT ? Un : a.U;
     const int lane = threadIdx.x & (WAVE - 1);
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (Un == 1) {   // no labels: prefix / suffix sums by one wave (uniform over the workgroup, no barrier yet)
+        if (w == 0) {
+            const size_t nb1 = COMPACT ? (size_t)a.offs[n] : (size_t)n * T * U;
+            const float2* lp2 = reinterpret_cast<const float2*>(a.lp) + nb1;
+            const float total = single_column_scan<BETA>(Tn, (BETA ? a.betas : a.alphas) + nb1, U, lane,
+                                                         [&](int t) { return lp2[(size_t)t * U].x; });
+            if (!BETA && lane == 0) a.ll[n] = total;
+        }
+        return;
+    }
     const int nA = blockDim.x >> 7;                   // compute waves = I/O waves
     const bool is_io = w >= nA;
     const int idx = is_io ? w - nA : w;               // column block
