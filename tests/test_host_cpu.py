@@ -177,3 +177,25 @@ def test_two_rank_reduction_gloo(tmp_path):
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, o
         assert f"rank {r} ok" in o
+
+
+def test_bench_configs_match_baseline_json():
+    """bench.py's workloads are BASELINE.json's configs[1..4] (per rank for the 8-GPU rows)."""
+    import importlib.util
+    import json
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    cfgs = json.load(open(os.path.join(root, "BASELINE.json")))["configs"]
+    for name, text in zip(("c2", "c3", "c4", "c5"), cfgs[1:5]):
+        n, t, u, v = (int(re.search(rf"\b{k}=(\d+)", text).group(1)) for k in ("N", "T", "U", "V"))
+        ranks = 8 if "8×MI355X" in text or "8xMI355X" in text else 1
+        N, T, U, V, gather, lam, _ = bench.CONFIGS[name]
+        assert (N * ranks, T, U, V) == (n, t, u, v), (name, text)
+        assert gather == ("gather=True" in text or "gather path" in text), (name, text)
+        if "fastemit_lambda=" in text:
+            assert abs(lam - float(re.search(r"fastemit_lambda=([0-9.]+)", text).group(1))) < 1e-9
+    # the default workload is the one the metric is quoted on (configs[3] per rank, README.md:51)
+    assert bench.parse.__defaults__ is None and "c4" in bench.CONFIGS
