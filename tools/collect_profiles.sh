@@ -22,4 +22,12 @@ rocprofv3 --pmc SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_I
 for l in warp-rnnt warp-rnnt-gather warp-rnnt-compact warp-rnnt-fused; do
   timeout 300 python $R/tools/benchmark_table.py --loss $l --markdown $OUT/table_$l.md > $OUT/table_$l.log 2>&1
 done
+# cache / memory counters of the loss kernels (gather, lattice, gradients), one --pmc pass per counter group
+i=0
+for set in "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum" "TCC_REQ_sum TCC_HIT_sum TCC_MISS_sum" \
+           "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum GRBM_GUI_ACTIVE" "TA_BUSY_avr TA_TA_BUSY_sum TCP_TA_TCP_STATE_READ_sum" \
+           "TCC_TAG_STALL_sum TCC_EA0_RDREQ_DRAM_sum TCC_BUSY_avr"; do
+  i=$((i+1))
+  rocprofv3 --pmc $set --kernel-trace --output-format csv -d $OUT/pmc_gather$i -o g -- python $R/tools/gather_probe.py $R/warp_rnnt_amd/libwarp_rnnt_amd.so > /dev/null 2>&1
+done
 ls $OUT

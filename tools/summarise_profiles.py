@@ -44,6 +44,8 @@ def main():
                                    os.path.join(DST, f"{TAG}_rocprof_{c}_kernel_stats.csv")])
     agg = pmc_summary(["pmc_fetch", "pmc_write"], os.path.join(DST, f"{TAG}_rocprof_c4_pmc_hbm.csv"))
     pmc_summary(["pmc_sq1", "pmc_sq2"], os.path.join(DST, f"{TAG}_rocprof_c4_pmc_sq.csv"))
+    if glob.glob(os.path.join(SRC, "pmc_gather1", "*_counter_collection.csv")):
+        pmc_summary([f"pmc_gather{i}" for i in range(1, 6)], os.path.join(DST, f"{TAG}_rocprof_c4_pmc_gather_path.csv"))
     for f in glob.glob(os.path.join(SRC, "table_*.md")):
         shutil.copy(f, os.path.join(DST, f"{TAG}_" + os.path.basename(f)))
     # HBM traffic of the dominant kernel, per launch (FETCH_SIZE doubled for wide coalesced reads)
@@ -60,6 +62,15 @@ def main():
             doc[cfg] = {"kernel": kname, "fetch_size_kib": f_kib, "write_size_kib": w_kib,
                         "traffic_bytes": f_kib * 2048 + w_kib * 1024}
     json.dump(doc, open(os.path.join(DST, "hbm_traffic.json"), "w"), indent=1)
+    # bench.py reads hbm_traffic.json at run time, i.e. the file of the PREVIOUS collection; fill a missing
+    # `roofline.traffic` from the PMC passes of this same collection
+    for cfg in ("c3", "c4"):
+        bj = os.path.join(DST, f"{TAG}_bench_{cfg}.json")
+        if cfg in doc and os.path.exists(bj):
+            d = json.load(open(bj))
+            if d.get("roofline", {}).get("traffic") is None:
+                d["roofline"]["traffic"] = doc[cfg]["traffic_bytes"]
+                json.dump(d, open(bj, "w"))
     print(sorted(os.listdir(DST)))
 
 
