@@ -49,7 +49,8 @@ typedef enum {
  *     the blank/label slots of live cells are written.
  *   counts (N,2U) uint32, alphas/betas (N,T,U) fp32: caller scratch, contents on
  *     return unspecified (alphas/betas hold the lattices in diagonal-major order,
- *     counts[n*2U] holds the alpha-side log-likelihood bits).  counts need not be zeroed.
+ *     the first N words of counts hold the alpha-side log-likelihoods as fp32 bits).  counts need
+ *     not be zeroed.
  *   costs (N,): out.
  * Lengths: the reference does not check 1 <= xn[n] <= T, 0 <= yn[n] <= U-1 (binding.cpp:47-51)
  *   and reads out of range when they are violated.  Every entry point of this library checks
@@ -93,6 +94,13 @@ enum {
 
 /* Bytes of device scratch rnnt_amd_loss needs for a problem of this size. */
 size_t rnnt_amd_workspace_size(int N, int T, int U);
+
+/* Byte offset, inside that workspace, of the (N,) int32 vector that rnnt_amd_loss fills with 1 where the
+ * forward/backward consistency guard fired (core_gather.cu:341-354: the alpha-side and beta-side
+ * log-likelihoods differ by more than 1e-3 relative; the reference prints a WARNING from the device,
+ * zeroes that utterance's gradients and returns the mean of the two as its cost -- the last two are
+ * reproduced, the message is replaced by this flag) or where the lengths were out of range. */
+size_t rnnt_amd_workspace_mismatch_offset(int N, int T, int U);
 
 /*
  * The loss: costs (N,) and gradients in one call.

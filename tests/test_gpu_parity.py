@@ -420,3 +420,109 @@ def test_long_utterance_without_labels_accuracy(gather):
     err_hip, err_ora = np.abs(g - g64).max(), np.abs(gref - g64).max()
     print(f"U_n=1, T_n={xn.tolist()}: max |grad - fp64|: hip {err_hip:.2e}, fp32 oracle {err_ora:.2e}")
     assert err_hip <= 3.0 * err_ora + 1e-5
+
+
+# ----------------------------------------------------------------------------
+# 9. the alpha/beta consistency guard (core_gather.cu:341-354; neither repository tested it before)
+# ----------------------------------------------------------------------------
+def _guard_case():
+    """T=1, U=4: the lattice is one chain of label emissions, summed left-to-right by the alpha sweep and
+    right-to-left by the beta sweep.  +-3e8 on the chain make fp32 absorb the -7 in one direction only
+    (and the final blank differently), so the two log-likelihoods come out as -2 and 0: ratio > 1e-3."""
+    N, T, U = 3, 1, 4
+    lp2 = np.full((N, T, U, 2), -1.0, dtype=np.float32)
+    lp2[1, 0, :, 1] = [3e8, -7.0, -3e8, 0.0]
+    lp2[1, 0, 3, 0] = -2.0
+    xn = np.ones((N,), dtype=np.int32)
+    yn = np.full((N,), U - 1, dtype=np.int32)
+    return lp2, xn, yn
+
+
+def test_mismatch_guard_fires_like_the_oracle():
+    from warp_rnnt_amd import ops
+    lp2, xn, yn = _guard_case()
+    ref = oracle.rnnt_loss_f32(lp2, None, xn, yn, blank=-1, scan_mode=1)
+    assert ref["mismatch"].tolist() == [0, 1, 0] and ref["costs"][1] == 1.0     # -( -2 + 0 ) / 2
+    # native op (diagonal-major kernels) with the flag vector read back
+    c, g, mism = ops.loss(t32(lp2), None, t32(xn), t32(yn), ops.IN_LOG_PROBS_GATHERED, ops.GRADS_GATHERED,
+                          -1, 0.0, return_mismatch=True)
+    assert mism.cpu().tolist() == [0, 1, 0]
+    np.testing.assert_array_equal(c.cpu().numpy(), ref["costs"])
+    np.testing.assert_allclose(g.cpu().numpy(), ref["grads"], atol=1e-6)
+    assert not g[1].any().item()
+    # reference C ABI, gathered and dense layouts (row-major loaders)
+    cb, gb = _call_ref_abi(lp2, np.zeros((3, 3), np.int32), xn, yn, -1, 0.0)
+    np.testing.assert_array_equal(cb, ref["costs"])
+    np.testing.assert_allclose(gb, ref["grads"], atol=1e-6)
+    V = 5
+    labels = np.array([[1, 2, 3]] * 3, dtype=np.int32)
+    dense = np.full((3, 1, 4, V), -9.0, dtype=np.float32)
+    dense[..., 0] = lp2[..., 0]
+    for u in range(3):
+        dense[:, 0, u, labels[0, u]] = lp2[:, 0, u, 1]
+    refd = oracle.rnnt_loss_f32(dense, labels, xn, yn, blank=0, scan_mode=1)
+    assert refd["mismatch"].tolist() == [0, 1, 0]
+    cd, gd = _call_ref_abi(dense, labels, xn, yn, 0, 0.0)
+    np.testing.assert_array_equal(cd, refd["costs"])
+    np.testing.assert_allclose(gd, refd["grads"], atol=1e-6)
+    assert not gd[1].any()
+
+
+def test_mismatch_policy_env(monkeypatch):
+    """WARP_RNNT_AMD_CHECK_MISMATCH surfaces the guard on the host (the reference prints from the device)."""
+    import warp_rnnt._C as core
+    lp2, xn, yn = _guard_case()
+    ys = torch.zeros((3, 3), dtype=torch.int32, device=dev())
+    monkeypatch.setenv("WARP_RNNT_AMD_CHECK_MISMATCH", "warn")
+    with pytest.warns(RuntimeWarning, match=r"utterance\(s\) \[1\]"):
+        core.rnnt_loss(t32(lp2), ys, t32(xn), t32(yn), blank=-1)
+    monkeypatch.setenv("WARP_RNNT_AMD_CHECK_MISMATCH", "raise")
+    with pytest.raises(RuntimeError, match="forward/backward mismatch"):
+        core.rnnt_loss(t32(lp2), ys, t32(xn), t32(yn), blank=-1)
+    monkeypatch.delenv("WARP_RNNT_AMD_CHECK_MISMATCH")
+    core.rnnt_loss(t32(lp2), ys, t32(xn), t32(yn), blank=-1)       # default: silent, flags stay on the device
+
+
+# ----------------------------------------------------------------------------
+# 10. label padding beyond yn[n] (ADVICE r1): the reference's dense path never reads it, so -1 or any
+#     sentinel is legal there; every entry point must give the bits it gives with a valid padding value
+# ----------------------------------------------------------------------------
+@pytest.mark.parametrize("V", [7, 1500])       # LDS-tile kernels / row-per-workgroup kernels
+@pytest.mark.parametrize("pad", [-1, "V+7"])
+def test_padded_labels_may_hold_any_sentinel(V, pad):
+    import warp_rnnt
+    from warp_rnnt_amd import ops
+    from warp_rnnt_amd.fused import rnnt_loss_from_logits
+    N, T, U = 4, 19, 9
+    logits, labels, xn, yn = make_case(321, N, T, U, V, ragged=True)
+    yn[0] = 0                                      # an utterance whose whole label row is padding
+    padv = V + 7 if pad == "V+7" else pad
+    bad = labels.copy()
+    for n in range(N):
+        bad[n, yn[n]:] = padv
+        labels[n, yn[n]:] = 1
+    lp = np_log_softmax32(logits)
+
+    def run(lab, how):
+        x = t32(lp if how != "fused" else logits).requires_grad_(True)
+        if how == "fused":
+            c = rnnt_loss_from_logits(x, t32(lab), t32(xn), t32(yn), fastemit_lambda=0.01)
+        else:
+            c = warp_rnnt.rnnt_loss(x, t32(lab), t32(xn), t32(yn), gather=(how == "gather"), fastemit_lambda=0.01)
+        (c * torch.arange(1, N + 1, device=dev())).sum().backward()
+        torch.cuda.synchronize()
+        return c.detach().cpu().numpy(), x.grad.cpu().numpy()
+
+    ref = oracle.rnnt_loss_f32(lp, labels, xn, yn, blank=0, fastemit_lambda=0.01, scan_mode=1)
+    for how in ("dense", "gather", "fused"):
+        c_ok, g_ok = run(labels, how)
+        c_bad, g_bad = run(bad, how)
+        np.testing.assert_array_equal(c_bad, c_ok, err_msg=how)
+        np.testing.assert_array_equal(g_bad, g_ok, err_msg=how)
+        np.testing.assert_allclose(c_ok, ref["costs"], rtol=COST_RTOL, err_msg=how)
+    # the row-major gather entry as well
+    out = ops.gather(t32(lp), t32(bad), 0).cpu().numpy()
+    good = oracle.gather_f32(lp, labels, 0)
+    for n in range(N):
+        np.testing.assert_array_equal(out[n, :, :yn[n] + 1, 0], good[n, :, :yn[n] + 1, 0])
+        np.testing.assert_array_equal(out[n, :, :yn[n], 1], good[n, :, :yn[n], 1])

@@ -199,3 +199,26 @@ def test_bench_configs_match_baseline_json():
             assert abs(lam - float(re.search(r"fastemit_lambda=([0-9.]+)", text).group(1))) < 1e-9
     # the default workload is the one the metric is quoted on (configs[3] per rank, README.md:51)
     assert bench.parse.__defaults__ is None and "c4" in bench.CONFIGS
+
+
+def test_bench_self_launches_ranks_gloo_dry():
+    """`python bench.py --gpus 2` with no launcher around it re-executes itself under torch.distributed.run
+    (one rank per GPU, 127.0.0.1 rendezvous) -- what the driver's SCALE runs invoke.  CPU rehearsal: gloo, no
+    kernels; the JSON line must come from rank 0 of a 2-rank group after a real all-reduce."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo",
+                          "--dry", "--steps", "2", "--warmup", "1"], env=env, stdout=subprocess.PIPE,
+                         stderr=subprocess.STDOUT, timeout=300)
+    text = out.stdout.decode()
+    assert out.returncode == 0, text
+    lines = [ln for ln in text.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, text
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["rccl_ranks"] == 2 and rec["dry"] is True
+    assert rec["reduced_scalar"] == 3.0            # 1 + 2: both ranks contributed
+    # a world size that contradicts --gpus is refused, not silently accepted
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry"],
+                         env=dict(env, WORLD_SIZE="1", RANK="0"), stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                         timeout=120)
+    assert bad.returncode != 0 and b"launcher started 1 rank" in bad.stdout

@@ -58,7 +58,7 @@ def rnnt_loss(xs, ys, xn, yn, blank=0, fastemit_lambda=0.0):
         if xs.size(3) != 2:
             raise RuntimeError("xs must have values only for blank and label")
         return _ops.loss(xs, None, xn, yn, _ops.IN_LOG_PROBS_GATHERED, _ops.GRADS_GATHERED,
-                         0, fastemit_lambda)
+                         -1, fastemit_lambda)
     return _ops.loss(xs, ys, xn, yn, _ops.IN_LOG_PROBS_DENSE, _ops.GRADS_DENSE, blank, fastemit_lambda)
 
 

@@ -23,6 +23,23 @@ def _hipcc():
     raise RuntimeError("hipcc not found (looked at $HIPCC, PATH, /opt/rocm/bin/hipcc)")
 
 
+def _read(path):
+    try:
+        with open(path) as f:
+            return f.read()
+    except OSError:
+        return None
+
+
+def _fingerprint(files, flags):
+    import hashlib
+    h = hashlib.sha256(" ".join(flags).encode())
+    for p in files:
+        with open(p, "rb") as f:
+            h.update(hashlib.sha256(f.read()).digest())
+    return h.hexdigest()
+
+
 def _stale(target, deps):
     if not os.path.exists(target):
         return True
@@ -30,14 +47,39 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=False, extra_flags=()):
+# A/B builds for the parity table (tests/test_gpu_baseline_sizes.py, profiles/r02_parity_errors.json);
+# select one at run time with WARP_RNNT_AMD_LIB=<path> (see _lib.lib_path).
+VARIANTS = {
+    # log-domain lattice, hardware exp2/log2 lse (the round-1 default), single-role kernel
+    "logdomain": ["-DRNNT_LATTICE_LOGDOMAIN"],
+    # the same with ocml expf/log1pf -- the reference's own lse (core.cu:26-39) bit for bit, 4x slower
+    "precise": ["-DRNNT_LATTICE_LOGDOMAIN", "-DRNNT_LATTICE_LEGACY", "-DRNNT_PRECISE_LIBM"],
+}
+
+
+def variant_path(variant):
+    return os.path.join(HERE, f"libwarp_rnnt_amd_{variant}.so")
+
+
+def build(force=False, verbose=False, extra_flags=(), variant=None):
     hipcc = _hipcc()
-    objdir = os.path.join(HERE, "build")
+    objdir = os.path.join(HERE, "build" if variant is None else "build_" + variant)
+    lib = LIB if variant is None else variant_path(variant)
+    if variant is not None:
+        extra_flags = list(VARIANTS[variant]) + list(extra_flags)
     os.makedirs(objdir, exist_ok=True)
     hdrs = [os.path.normpath(os.path.join(CSRC, h)) for h in HEADERS]
     flags = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
              "-fno-slp-vectorize"]   # the lattice chains must stay scalar (v_pk_add_f32 costs two issue slots)
     flags += list(extra_flags)
+
+    srcs = [os.path.join(CSRC, x) for x in SOURCES]
+    fp = _fingerprint(srcs + hdrs, flags)
+    if not force and os.path.exists(lib) and _read(lib + ".fingerprint") == fp:
+        # built from exactly these sources with exactly these flags: nothing to do, even when the object
+        # files are absent and whatever the file times say (only the .so and this sidecar travel to the
+        # GPU box, and a snapshot copy need not preserve mtimes)
+        return lib
 
     def compile_one(src):
         s = os.path.join(CSRC, src)
@@ -51,12 +93,14 @@ def build(force=False, verbose=False, extra_flags=()):
 
     with ThreadPoolExecutor(max_workers=len(SOURCES)) as ex:
         objs = list(ex.map(compile_one, SOURCES))
-    if force or _stale(LIB, objs):
-        cmd = [hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs
+    if force or _stale(lib, objs) or _read(lib + ".fingerprint") != fp:
+        cmd = [hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", lib] + objs
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
-    return LIB
+        with open(lib + ".fingerprint", "w") as f:
+            f.write(fp)
+    return lib
 
 
 def ensure_built():
@@ -77,4 +121,5 @@ def ensure_built():
 
 
 if __name__ == "__main__":
-    print(build(verbose=True))
+    import sys
+    print(build(verbose=True, variant=sys.argv[1] if len(sys.argv) > 1 else None))

@@ -28,6 +28,7 @@ SYMBOLS = {
     "run_warp_rnnt": (_i, [_vp] * 10 + [_i] * 5 + [_f]),
     "run_warp_rnnt_gather": (_i, [_vp] * 9 + [_i] * 3 + [_f]),
     "rnnt_amd_workspace_size": (_sz, [_i, _i, _i]),
+    "rnnt_amd_workspace_mismatch_offset": (_sz, [_i, _i, _i]),
     "rnnt_amd_loss": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f]),
     "rnnt_amd_expand_grads": (_i, [_vp] * 7 + [_i] * 6),
     "rnnt_amd_logits_backward": (_i, [_vp] * 6 + [_i] * 5),
@@ -48,7 +49,9 @@ class RNNTStatusError(RuntimeError):
 
 
 def lib_path():
-    return os.path.join(HERE, _LIB_NAME)
+    """The in-tree library; WARP_RNNT_AMD_LIB selects another build of the same C ABI (the A/B variants
+    of _build.VARIANTS used for the parity table) -- still a HIP build, still no fallback."""
+    return os.environ.get("WARP_RNNT_AMD_LIB") or os.path.join(HERE, _LIB_NAME)
 
 
 def load():

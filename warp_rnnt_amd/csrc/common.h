@@ -81,6 +81,14 @@ __device__ __forceinline__ float single_column_scan(const int Tn, float* __restr
     return carry;
 }
 
+// Label of a lattice column as a vocabulary index that is always safe to address with.  Entries beyond
+// yn[n] are padding: the reference's dense path and C ABI never read them (kernel_grads_label returns
+// early, core.cu:305-309), so callers pad with -1 or any sentinel.  Nothing a padded column reads or
+// writes reaches a result (its cells are dead), so it is simply pointed at the blank slot.
+__device__ __forceinline__ int safe_label(int lab, int V, int blank) {
+    return (unsigned)lab < (unsigned)V ? lab : blank;
+}
+
 // How a kernel finds the blank / label log-probability of lattice cell (t,u).
 enum Loader : int {
     LOAD_SKEWED = 0,   // float2 workspace, diagonal-major (internal layout)

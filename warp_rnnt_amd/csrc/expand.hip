@@ -33,7 +33,7 @@ struct ExpandCell {
 __device__ __forceinline__ ExpandCell expand_cell(unsigned cell, const float2* __restrict__ g2,
                                                   const int* __restrict__ labels, const int* __restrict__ xn,
                                                   const int* __restrict__ yn, const float* __restrict__ scale,
-                                                  int T, int U, int blank, int overwrite) {
+                                                  int T, int U, int V, int blank, int overwrite) {
     const unsigned frame = cell / (unsigned)U;
     const int u = (int)(cell - frame * (unsigned)U);
     const unsigned n = frame / (unsigned)T;
@@ -46,6 +46,7 @@ __device__ __forceinline__ ExpandCell expand_cell(unsigned cell, const float2* _
     c.gB = g.x * sc;
     c.gL = g.y * sc;
     c.lab = (u < U - 1) ? labels[(size_t)n * (U - 1) + u] : blank;
+    if ((unsigned)c.lab >= (unsigned)V) c.lab = -1;   // padding beyond yn[n] (-1 or any sentinel): its gL is 0
     if (overwrite) {
         // dense-kernel rule (core.cu:382-393): the label slot is written only for live cells with a
         // label, after the blank slot
@@ -60,14 +61,14 @@ __device__ __forceinline__ ExpandCell expand_cell(unsigned cell, const float2* _
 // Row sources: where row `i` of the dense output gets its two values from.
 struct PaddedRows {    // (N,T,U,V) output, diagonal-major pairs (gather backward / dense forward)
     const float2* g2; const int* labels; const int* xn; const int* yn; const float* scale;
-    int T, U, blank, overwrite;
+    int T, U, V, blank, overwrite;
     __device__ __forceinline__ ExpandCell operator()(unsigned row) const {
-        return expand_cell(row, g2, labels, xn, yn, scale, T, U, blank, overwrite);
+        return expand_cell(row, g2, labels, xn, yn, scale, T, U, V, blank, overwrite);
     }
 };
 struct CompactRows {   // (STU,V) output, row-major pairs + loc (core_compact.cu:456-484)
     const float2* g2; const int64_t* loc; const int* cum_lens; const float* grad_cost;
-    int N, blank;
+    int N, V, blank;
     __device__ __forceinline__ ExpandCell operator()(unsigned row) const {
         // utterance of this row: first n with cum_lens[n] > row (inclusive prefix sums)
         int lo = 0, hi = N - 1;
@@ -81,7 +82,7 @@ struct CompactRows {   // (STU,V) output, row-major pairs + loc (core_compact.cu
         c.gB = g.x * sc;
         c.gL = g.y * sc;
         c.lab = (int)loc[row];
-        if (c.lab == blank) c.lab = -1;        // the reference writes the label slot only if loc != blank
+        if (c.lab == blank || (unsigned)c.lab >= (unsigned)V) c.lab = -1;        // the reference writes the label slot only if loc != blank
         return c;
     }
 };
@@ -159,7 +160,7 @@ hipError_t launch_expand(hipStream_t stream, const float* g2_skewed, const int* 
                          int blank, int overwrite_mode) {
     const size_t cells64 = (size_t)N * T * U;
     if (cells64 == 0 || V == 0) return hipSuccess;
-    const PaddedRows rows{reinterpret_cast<const float2*>(g2_skewed), labels, xn, yn, scale, T, U, blank,
+    const PaddedRows rows{reinterpret_cast<const float2*>(g2_skewed), labels, xn, yn, scale, T, U, V, blank,
                           overwrite_mode};
     return launch_rows(stream, rows, dense, (unsigned)cells64, V, blank);
 }
@@ -170,7 +171,7 @@ hipError_t launch_scatter_compact(hipStream_t stream, const float* grad_cost, co
                                   int V, int blank) {
     if (STU <= 0 || V <= 0) return hipSuccess;
     if (STU >= ((int64_t)1 << 32)) return hipErrorInvalidValue;
-    const CompactRows rows{reinterpret_cast<const float2*>(grads2), loc, cum_lens, grad_cost, N, blank};
+    const CompactRows rows{reinterpret_cast<const float2*>(grads2), loc, cum_lens, grad_cost, N, V, blank};
     return launch_rows(stream, rows, out, (unsigned)STU, V, blank);
 }
 

@@ -67,7 +67,7 @@ __global__ void __launch_bounds__(256) k_grads(const GradArgs a) {
         } else {
             const float* p = a.lp + (nb + (size_t)t * U + u) * (size_t)a.V;
             lpB = p[a.blank];
-            lpL = (u < Un - 1) ? p[a.labels[(size_t)n * (U - 1) + u]] : 0.0f;
+            lpL = (u < Un - 1) ? p[safe_label(a.labels[(size_t)n * (U - 1) + u], a.V, a.blank)] : 0.0f;
         }
         const float alpha = al[idx];
         const int r1 = (r + 1 == T) ? 0 : r + 1;
@@ -94,7 +94,7 @@ __global__ void __launch_bounds__(256) k_grads(const GradArgs a) {
         if (valid) {
             float* g = a.grads + (nb + (size_t)t * U + u) * (size_t)a.V;
             if (t < Tn - 1 || u == Un - 1) g[a.blank] = gB;
-            if (u < Un - 1) g[a.labels[(size_t)n * (U - 1) + u]] = gL;
+            if (u < Un - 1) g[safe_label(a.labels[(size_t)n * (U - 1) + u], a.V, a.blank)] = gL;
         }
     }
 }

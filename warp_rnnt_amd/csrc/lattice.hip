@@ -258,7 +258,7 @@ __device__ __forceinline__ void sweep(const LatticeArgs& a, const int n, float (
         const int ucol_chk = colvalid ? ucol : 0x40000000;  // makes the live predicate false
         int lab = -1;
         if constexpr (LOADER == LOAD_DENSE) {
-            if (uc < U - 1) lab = a.labels[(size_t)n * (U - 1) + uc];
+            if (uc < U - 1) lab = safe_label(a.labels[(size_t)n * (U - 1) + uc], a.V, a.blank);
         }
         const int nwa = min(nw, (Un - c0 + WAVE - 1) / WAVE);  // waves with a live column
         const int wave_c = c0 + WAVE * w;                      // first sweep column of this wave
@@ -326,7 +326,7 @@ __device__ __forceinline__ void sweep(const LatticeArgs& a, const int n, float (
                         float v = out[(size_t)rb * U + ub];
                         if constexpr (!BETA) {
                             int labb = -1;
-                            if constexpr (LOADER == LOAD_DENSE) labb = a.labels[(size_t)n * (U - 1) + ub];
+                            if constexpr (LOADER == LOAD_DENSE) labb = safe_label(a.labels[(size_t)n * (U - 1) + ub], a.V, a.blank);
                             v += load_cell<LOADER>(a, rs_lp, nbase, U, rb, dd - (c0 - 1), ub, labb).l;
                         }
                         mvec = v;

@@ -22,6 +22,7 @@
 //                    stores values(p-3) LDS -> HBM
 //   compute    at p: computes local block lb = p-2 (its pairs were read from LDS during p-1),
 //                    prefetches pairs(lb+1) from LDS, writes values(lb) to LDS
+#include <atomic>
 #include <type_traits>
 
 #include "common.h"
@@ -362,18 +363,21 @@ hipError_t launch_lattice_ws(hipStream_t stream, const LatticeArgs& a, int N) {
     if (nA > ws::MAXA) return hipErrorNotSupported;
     const size_t lds = sizeof(ws::Smem) * nA;
     const dim3 grid(2 * N), block(2 * nA * WAVE);
-    // > 64 KiB of dynamic LDS needs an opt-in per kernel and per device (one-time, idempotent)
-    static bool attr_set[2][64] = {};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    // > 64 KiB of dynamic LDS needs an opt-in per kernel and per device.  hipFuncSetAttribute is idempotent
+    // and thread-safe, so the only state kept is a per-(kernel, device) "already done" bit; devices beyond
+    // the table simply repeat the call every launch.
+    static std::atomic<bool> attr_set[2][64];
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess) dev = -1;
     const int ci = a.offs ? 1 : 0;
-    if (!attr_set[ci][dev]) {
+    const bool tracked = dev >= 0 && dev < 64;
+    if (!tracked || !attr_set[ci][dev].load(std::memory_order_acquire)) {
         const void* fn = a.offs ? reinterpret_cast<const void*>(&ws::k_lattice_ws<true>)
                                 : reinterpret_cast<const void*>(&ws::k_lattice_ws<false>);
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize,
                                            (int)(sizeof(ws::Smem) * ws::MAXA));
         if (e != hipSuccess) return e;
-        attr_set[ci][dev] = true;
+        if (tracked) attr_set[ci][dev].store(true, std::memory_order_release);
     }
     if (a.offs)
         ws::k_lattice_ws<true><<<grid, block, lds, stream>>>(a);

@@ -43,7 +43,7 @@ struct CellMap {
     int n;       // utterance
 };
 __device__ __forceinline__ CellMap map_cell(size_t cell, const int* __restrict__ labels, int T, int U,
-                                            int blank) {
+                                            int V, int blank) {
     // N*T*U < 2^32 is checked by the C ABI, so 32-bit divisions are enough
     const unsigned c32 = (unsigned)cell;
     const unsigned frame = c32 / (unsigned)U;         // n*T + t
@@ -54,7 +54,7 @@ __device__ __forceinline__ CellMap map_cell(size_t cell, const int* __restrict__
     r = r >= T ? r % T : r;
     CellMap m;
     m.sk = ((size_t)n * T + r) * (size_t)U + u;
-    m.label = (u < U - 1) ? labels[(size_t)n * (U - 1) + u] : blank;
+    m.label = (u < U - 1) ? safe_label(labels[(size_t)n * (U - 1) + u], V, blank) : blank;
     m.n = (int)n;
     return m;
 }
@@ -177,7 +177,7 @@ k_lsm_small(const float* x, float* out, const int* __restrict__ labels,
         if constexpr (GATHER) {
             if (h == 0) stat[r] = make_float2(mx, ls);
         } else if constexpr (MODE == LSM_BWD) {
-            const CellMap m = map_cell((size_t)(row0 + r), labels, T, U, blank);
+            const CellMap m = map_cell((size_t)(row0 + r), labels, T, U, V, blank);
             const float sc = bw.scale ? bw.scale[m.n] : 1.0f;
             const float2 g = bw.g2[m.sk];
             const float gB = g.x * sc, gL = g.y * sc, gs = gB + gL;
@@ -195,7 +195,7 @@ k_lsm_small(const float* x, float* out, const int* __restrict__ labels,
     if constexpr (GATHER && WP) {
         wave_sync_lds();
         for (int r = wr0 + lane; r < wr0 + wn; r += WAVE) {
-            const CellMap m = map_cell((size_t)(row0 + r), labels, T, U, blank);
+            const CellMap m = map_cell((size_t)(row0 + r), labels, T, U, V, blank);
             const float2 st = stat[r];
             const float* row = tile + r * V;
             reinterpret_cast<float2*>(out)[m.sk] =
@@ -206,7 +206,7 @@ k_lsm_small(const float* x, float* out, const int* __restrict__ labels,
         // doing it inside the L-lane row loop ran it with a quarter of the lanes)
         __syncthreads();
         for (int r = tid; r < nrows; r += SM_THREADS) {
-            const CellMap m = map_cell((size_t)(row0 + r), labels, T, U, blank);
+            const CellMap m = map_cell((size_t)(row0 + r), labels, T, U, V, blank);
             const float2 st = stat[r];
             const float* row = tile + r * V;
             reinterpret_cast<float2*>(out)[m.sk] =
@@ -283,13 +283,13 @@ k_lsm_large(const float* x, float* out, const int* __restrict__ labels,
     const float ls = logf(s);
     if constexpr (GATHER) {
         if (threadIdx.x == 0) {
-            const CellMap m = map_cell(row, labels, T, U, blank);
+            const CellMap m = map_cell(row, labels, T, U, V, blank);
             const float* xr = x + row * V;
             reinterpret_cast<float2*>(out)[m.sk] =
                 make_float2((xr[blank] - mx) - ls, (xr[m.label] - mx) - ls);
         }
     } else if constexpr (MODE == LSM_BWD) {
-        const CellMap m = map_cell(row, labels, T, U, blank);
+        const CellMap m = map_cell(row, labels, T, U, V, blank);
         const float sc = bw.scale ? bw.scale[m.n] : 1.0f;
         const float2 g = bw.g2[m.sk];
         const float gB = g.x * sc, gL = g.y * sc, gs = gB + gL;
@@ -345,12 +345,12 @@ k_lsm_generic(const float* x, float* out, const int* __restrict__ labels,
     const float ls = logf(s);
     if constexpr (GATHER) {
         if (lane == 0) {
-            const CellMap m = map_cell((size_t)row, labels, T, U, blank);
+            const CellMap m = map_cell((size_t)row, labels, T, U, V, blank);
             reinterpret_cast<float2*>(out)[m.sk] =
                 make_float2((xr[blank] - mx) - ls, (xr[m.label] - mx) - ls);
         }
     } else if constexpr (MODE == LSM_BWD) {
-        const CellMap m = map_cell((size_t)row, labels, T, U, blank);
+        const CellMap m = map_cell((size_t)row, labels, T, U, V, blank);
         const float sc = bw.scale ? bw.scale[m.n] : 1.0f;
         const float2 g = bw.g2[m.sk];
         const float gB = g.x * sc, gL = g.y * sc, gs = gB + gL;
@@ -602,7 +602,7 @@ k_to_diagonal(const float* __restrict__ src, const int* __restrict__ labels, flo
     const int u = u0 + ul;
     const size_t nbase = (size_t)n * T * U;
     int lab = blank;
-    if (DENSE && u < U - 1) lab = labels[(size_t)n * (U - 1) + u];
+    if (DENSE && u < U - 1) lab = safe_label(labels[(size_t)n * (U - 1) + u], V, blank);
 #pragma unroll
     for (int k = 0; k < TT / 8; ++k) {
         const int tl = tl0 + 8 * k, t = t0 + tl;
@@ -640,7 +640,7 @@ k_gather_rowmajor(const float* __restrict__ lp, const int* __restrict__ labels, 
                   size_t cells, int T, int U, int V, int blank) {
     const size_t cell = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (cell >= cells) return;
-    const CellMap m = map_cell(cell, labels, T, U, blank);
+    const CellMap m = map_cell(cell, labels, T, U, V, blank);
     const float* p = lp + cell * (size_t)V;
     out2[cell] = make_float2(p[blank], p[m.label]);
 }
@@ -700,7 +700,7 @@ k_gather_compact(const float* __restrict__ xs, const int* __restrict__ ys, const
     const int u = u0 + ul;
     const size_t nbase = (size_t)offs[n];
     int lab = blank;
-    if (u < U - 1) lab = ys[label_offs[n] + u];
+    if (u < U - 1) lab = safe_label(ys[label_offs[n] + u], V, blank);
 #pragma unroll
     for (int k = 0; k < TD / 8; ++k) {
         const int tl = tl0 + 8 * k, t = t0 + tl;

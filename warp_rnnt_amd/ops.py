@@ -1,4 +1,7 @@
 """Torch-tensor front ends of the native entry points (device memory + streams only)."""
+import os
+import warnings
+
 import torch
 
 from . import _lib
@@ -21,12 +24,26 @@ def _check(status):
                            " (" + STATUS_NAMES.get(status, "?") + ")")
 
 
-def loss(input, labels, xn, yn, input_kind, grads_kind, blank=0, fastemit_lambda=0.0):
-    """costs (N,), grads (layout per grads_kind; None for GRADS_NONE). Tensors must be validated
-    by the caller (contiguous, fp32/int32, same GPU)."""
+def _mismatch_policy():
+    """WARP_RNNT_AMD_CHECK_MISMATCH = warn | raise: read the guard flags back after every loss call
+    (one host synchronisation) -- the counterpart of the reference's device-side WARNING printf
+    (core_gather.cu:345-349).  Unset (default): no read-back, the flags stay on the device."""
+    return os.environ.get("WARP_RNNT_AMD_CHECK_MISMATCH", "").lower()
+
+
+def loss(input, labels, xn, yn, input_kind, grads_kind, blank=0, fastemit_lambda=0.0, return_mismatch=False):
+    """costs (N,), grads (layout per grads_kind; None for GRADS_NONE) [, mismatch (N,) int32].
+    Tensors must be validated by the caller (contiguous, fp32/int32, same GPU).  ``mismatch[n]`` is 1
+    where the forward/backward consistency guard zeroed an utterance's gradients (or its lengths were
+    out of range)."""
     L = _lib.load()
     N, T, U, V = input.shape
     dev = input.device
+    if input_kind == IN_LOG_PROBS_GATHERED:
+        blank = 0          # channel 0 of the 2-channel layout; the caller's blank is -1 by convention
+    elif not 0 <= blank < V:
+        raise RuntimeError(f"rnnt_loss status 5 (RNNT_STATUS_INVALID_ARGUMENT): blank={blank} is not a "
+                           f"vocabulary index of xs (V={V})")
     with torch.cuda.device(dev):
         costs = torch.empty((N,), dtype=torch.float32, device=dev)
         if grads_kind == GRADS_DENSE:
@@ -36,6 +53,8 @@ def loss(input, labels, xn, yn, input_kind, grads_kind, blank=0, fastemit_lambda
         else:
             grads = torch.empty((N, T, U, 2), dtype=torch.float32, device=dev)
         if N == 0:
+            if return_mismatch:
+                return costs, grads, torch.zeros((0,), dtype=torch.int32, device=dev)
             return costs, grads
         ws_bytes = L.rnnt_amd_workspace_size(N, T, U)
         if ws_bytes == 0:
@@ -44,8 +63,22 @@ def loss(input, labels, xn, yn, input_kind, grads_kind, blank=0, fastemit_lambda
         ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
         st = L.rnnt_amd_loss(_stream(dev), ws.data_ptr(), input_kind, input.data_ptr(), _ptr(labels),
                              xn.data_ptr(), yn.data_ptr(), costs.data_ptr(), _ptr(grads), grads_kind,
-                             N, T, U, V, max(blank, 0), float(fastemit_lambda))
+                             N, T, U, V, blank, float(fastemit_lambda))
         _check(st)
+        policy = _mismatch_policy()
+        if return_mismatch or policy:
+            off = L.rnnt_amd_workspace_mismatch_offset(N, T, U)
+            mismatch = ws[off:off + 4 * N].view(torch.int32).clone()
+            if policy:
+                bad = mismatch.nonzero().flatten().tolist()      # host synchronisation (opt-in)
+                if bad:
+                    msg = (f"rnnt_loss: forward/backward mismatch or invalid lengths for utterance(s) {bad}: "
+                           "their gradients are zero (core_gather.cu:341-354)")
+                    if policy == "raise":
+                        raise RuntimeError(msg)
+                    warnings.warn(msg, RuntimeWarning, stacklevel=2)
+            if return_mismatch:
+                return costs, grads, mismatch
     return costs, grads
 
 
