@@ -152,9 +152,13 @@ def test_seeded_vs_oracle_all_entry_points(N, T, U, V, ragged, lam, blank):
     cb, gb = _call_ref_abi(lp2, labels, xn, yn, -1, lam)
     np.testing.assert_allclose(cb, ref2["costs"], rtol=COST_RTOL)
     np.testing.assert_allclose(gb, ref2["grads"], atol=GRAD_ATOL)
-    np.testing.assert_array_equal(ca, c)
-    np.testing.assert_array_equal(ga, g)
-    np.testing.assert_array_equal(gb, g2)
+    # the reference-named entry points run the log-domain kernels on the caller's layout (lattice.hip), the
+    # native op the probability-domain kernel on the diagonal-major workspace: same results to fp32 accuracy,
+    # bit-equal within each family
+    np.testing.assert_array_equal(ca, cb)
+    np.testing.assert_allclose(ca, c, rtol=COST_RTOL)
+    np.testing.assert_allclose(ga, g, atol=GRAD_ATOL)
+    np.testing.assert_allclose(gb, g2, atol=GRAD_ATOL)
 
 
 def test_calls_stress():

@@ -26,7 +26,7 @@ def build_variant(name, flags):
     objs = []
     for src in _build.SOURCES:
         o = os.path.join(objdir, src.replace(".hip", ".o"))
-        subprocess.check_call([_build._hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"] + flags +
+        subprocess.check_call([_build._hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-slp-vectorize"] + flags +
                               ["-c", os.path.join(_build.CSRC, src), "-o", o])
         objs.append(o)
     subprocess.check_call([_build._hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs)

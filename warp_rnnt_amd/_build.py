@@ -11,7 +11,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libwarp_rnnt_amd.so")
-SOURCES = ["api.hip", "lattice.hip", "lattice_ws.hip", "grads.hip", "prologue.hip", "expand.hip"]
+SOURCES = ["api.hip", "lattice.hip", "lattice_ws.hip", "lattice_pd.hip", "grads.hip", "prologue.hip", "expand.hip"]
 HEADERS = ["common.h", "kernels.h", os.path.join("..", "..", "include", "warp_rnnt_amd.h")]
 ARCH = "gfx950"
 

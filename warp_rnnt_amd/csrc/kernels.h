@@ -16,6 +16,9 @@ struct LatticeArgs {
     int T, U, V, blank;   // V/blank: LOAD_DENSE only
     const int64_t* offs;  // compact layout: (N+1,) cell offset of each utterance's (T_n, U_n) plane;
                           // nullptr = padded (N,T,U) planes
+    int* redo;            // (2N,) [2n+dir]: written by the probability-domain kernel (1 = inputs outside the range
+                          // it can represent), read by the log-domain kernel launched behind it (0 = nothing to do);
+                          // nullptr = log-domain kernel only
 };
 
 struct GradArgs {
@@ -35,8 +38,11 @@ struct GradArgs {
 };
 
 hipError_t launch_lattice(hipStream_t stream, const LatticeArgs& a, int N, int loader);
-// wave-specialised variant (diagonal-major loader only); hipErrorNotSupported when U > 512
+// wave-specialised log-domain variant (diagonal-major loader only); hipErrorNotSupported when U > 512.
+// With a.redo set only the (utterance, direction) pairs flagged there are swept.
 hipError_t launch_lattice_ws(hipStream_t stream, const LatticeArgs& a, int N);
+// probability-domain variant (lattice_pd.hip; diagonal-major loader, needs a.redo); hipErrorNotSupported when U > 320
+hipError_t launch_lattice_pd(hipStream_t stream, const LatticeArgs& a, int N);
 hipError_t launch_grads(hipStream_t stream, const GradArgs& a, int N, int loader, int writer);
 
 // prologue / epilogue streaming kernels

@@ -24,6 +24,7 @@
 //     block ahead; alphas/betas are written in the same diagonal-major layout
 //     with coalesced stores.
 //   Critical path: (T_n + U_n - 1) + K*(waves-1) dependent lse steps.
+#include <cstdlib>
 #include <type_traits>
 
 #include "common.h"
@@ -444,8 +445,21 @@ hipError_t launch_lattice(hipStream_t stream, const LatticeArgs& a, int N, int l
     if (N <= 0) return hipSuccess;
 #ifndef RNNT_LATTICE_LEGACY
     if (loader == LOAD_SKEWED) {
-        // preferred: compute / I/O wave pairs (lattice_ws.hip); one pass covers U <= 512
-        const hipError_t e = launch_lattice_ws(stream, a, N);
+#ifndef RNNT_LATTICE_LOGDOMAIN
+        // preferred: probability-domain sweep (lattice_pd.hip, U <= 320), followed by the log-domain kernel for
+        // the (utterance, direction) pairs whose inputs it flagged -- normally none: those workgroups return
+        // at once
+        static const bool pd_off = getenv("RNNT_LATTICE_LOGDOMAIN") != nullptr;   // A/B switch, read once
+        if (a.redo && !pd_off) {
+            const hipError_t e = launch_lattice_pd(stream, a, N);
+            if (e == hipSuccess) return launch_lattice_ws(stream, a, N);
+            if (e != hipErrorNotSupported) return e;
+        }
+#endif
+        // log-domain compute / I/O wave pairs (lattice_ws.hip); one pass covers U <= 512
+        LatticeArgs b = a;
+        b.redo = nullptr;
+        const hipError_t e = launch_lattice_ws(stream, b, N);
         if (e != hipErrorNotSupported) return e;
     }
 #endif

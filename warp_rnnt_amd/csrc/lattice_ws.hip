@@ -347,6 +347,7 @@ __global__ void __launch_bounds__(2 * MAXA * WAVE) k_lattice_ws(const LatticeArg
     unsigned n, dir;
     if ((grp << 3) + 8 <= pairs_total) { n = (grp << 3) + (in & 7); dir = in >> 3; }
     else { const unsigned r = b - (grp << 4); n = (grp << 3) + (r >> 1); dir = r & 1; }   // tail group
+    if (a.redo && a.redo[2 * n + dir] == 0) return;   // swept by the probability-domain kernel (uniform)
     if (dir)
         sweep<true, COMPACT>(a, n, smem);
     else
