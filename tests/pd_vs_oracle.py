@@ -1,0 +1,83 @@
+"""Runs in a subprocess of tests/test_gpu_pd.py with RNNT_LATTICE=pd: the probability-domain lattice kernel
+(csrc/lattice_pd.hip) forced on for every shape it supports, against the fp32 oracle -- including the shapes
+around its structural boundaries (column blocks of 64 = workgroups, blocks of 8 diagonals, late-starting and
+early-finishing lanes), inputs it must hand to the log-domain kernel, and repeated launches on one workspace
+(launch epochs of the hand-over rings)."""
+import os
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+sys.path.insert(0, HERE)
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+import oracle  # noqa: E402
+from helpers import make_case, np_log_softmax32  # noqa: E402
+
+
+def t32(a):
+    return torch.tensor(np.ascontiguousarray(a), device="cuda:0")
+
+
+def native(lp2, xn, yn, lam=0.0, want_mismatch=False):
+    from warp_rnnt_amd import ops
+    out = ops.loss(t32(lp2), None, t32(xn), t32(yn), ops.IN_LOG_PROBS_GATHERED, ops.GRADS_GATHERED, -1, lam,
+                   return_mismatch=want_mismatch)
+    torch.cuda.synchronize()
+    return [o.cpu().numpy() for o in out]
+
+
+def check(name, lp2, xn, yn, lam=0.0, grad_atol=None):
+    ref = oracle.rnnt_loss_f32(lp2, None, xn, yn, blank=-1, fastemit_lambda=lam, scan_mode=1)
+    c, g = native(lp2, xn, yn, lam)
+    np.testing.assert_allclose(c, ref["costs"], rtol=1e-5, err_msg=name)
+    # gradients are exp(alpha + beta + lp - loglik): fp32 noise of the ORACLE's log-domain sums grows with |loglik|
+    # (one ulp at 250 is 1.5e-5, and it adds a few of them)
+    if grad_atol is None:
+        grad_atol = 1e-4 * max(1.0, float(np.abs(ref["costs"]).max()) / 100.0)
+    np.testing.assert_allclose(g, ref["grads"], atol=grad_atol, err_msg=name)
+
+
+def main():
+    assert os.environ.get("RNNT_LATTICE") == "pd"
+    rng = np.random.RandomState(5)
+    shapes = [(3, t, u) for u in (2, 31, 63, 64, 65, 127, 128, 129, 200) for t in (1, 2, 7, 8, 9, 33)]
+    shapes += [(2, 20, 511), (2, 20, 512), (2, 257, 300), (1, 40, 320), (4, 150, 40), (2, 300, 257), (2, 70, 1),
+               (5, 7, 5), (2, 3, 70), (2, 90, 200)]
+    for i, (N, T, U) in enumerate(shapes):
+        V = int(rng.choice([2, 3, 5, 9])) if U > 1 else 3
+        logits, labels, xn, yn = make_case(2000 + i, N, T, U, V, ragged=bool(i % 2))
+        lp2 = oracle.gather_f32(np_log_softmax32(logits), labels, 0)
+        check(f"shape {N},{T},{U} ragged={i % 2}", lp2, xn, yn, lam=0.0 if i % 3 else 0.02)
+    # a long lattice, twice on purpose (second launch: new epoch, same rings)
+    logits, labels, xn, yn = make_case(77, 2, 700, 300, 6, ragged=True)
+    lp2 = oracle.gather_f32(np_log_softmax32(logits), labels, 0)
+    for _ in range(2):
+        # |log-likelihood| ~ 1e3: two fp32 implementations differ by a few 1e-4 there; the oracle is the looser one
+        check("long 700x300", lp2, xn, yn, grad_atol=2e-3)
+    # inputs the probability domain cannot carry: -inf, a log-prob below -80, +3e8 (the guard case of
+    # test_gpu_parity.py) -- every one must come back exactly as the log-domain kernel computes it
+    logits, labels, xn, yn = make_case(78, 4, 40, 70, 5)
+    lp2 = oracle.gather_f32(np_log_softmax32(logits), labels, 0)
+    lp2[1, 3, 4, 1] = -95.0
+    lp2[2, 7, 2, 0] = -1000.0
+    lp2[3, 9, 69, 1] = -3.0e4          # label channel of the last column: not part of the lattice, must not matter
+    os.environ.pop("RNNT_LATTICE")     # (read once by the library: this changes nothing for this process)
+    ref = oracle.rnnt_loss_f32(lp2, None, xn, yn, blank=-1, scan_mode=1)
+    c, g = native(lp2, xn, yn)
+    np.testing.assert_allclose(c, ref["costs"], rtol=1e-5)
+    np.testing.assert_allclose(g, ref["grads"], atol=1e-4)
+    lpg = np.full((3, 1, 4, 2), -1.0, dtype=np.float32)
+    lpg[1, 0, :, 1] = [3e8, -7.0, -3e8, 0.0]
+    lpg[1, 0, 3, 0] = -2.0
+    one, three = np.ones((3,), np.int32), np.full((3,), 3, np.int32)
+    ref = oracle.rnnt_loss_f32(lpg, None, one, three, blank=-1, scan_mode=1)
+    c, g, mism = native(lpg, one, three, want_mismatch=True)
+    assert mism.tolist() == [0, 1, 0] == ref["mismatch"].tolist()
+    np.testing.assert_array_equal(c, ref["costs"])
+    print("PD_VS_ORACLE_OK")
+
+
+if __name__ == "__main__":
+    main()

@@ -18,7 +18,8 @@ struct Workspace {
     float* ws2;      // diagonal-major (blank,label) pairs; later the gathered grads
     float* ll;
     int* mismatch;
-    int* redo;       // (2N,) hand-over between the two lattice kernels (kernels.h)
+    int* redo;       // (2N,) hand-over between the two lattice kernels, followed by the work-item counter
+    unsigned long long* mail;   // boundary-column rings of the probability-domain lattice kernel (kernels.h)
 };
 
 size_t carve(void* base, int N, int T, int U, Workspace* w) {
@@ -31,8 +32,9 @@ size_t carve(void* base, int N, int T, int U, Workspace* w) {
     float* ws2 = reinterpret_cast<float*>(take(cells * 2 * sizeof(float)));
     float* ll = reinterpret_cast<float*>(take((size_t)N * sizeof(float)));
     int* mismatch = reinterpret_cast<int*>(take((size_t)N * sizeof(int)));
-    int* redo = reinterpret_cast<int*>(take((size_t)N * 2 * sizeof(int)));
-    if (w) *w = Workspace{alphas, betas, ws2, ll, mismatch, redo};
+    int* redo = reinterpret_cast<int*>(take(((size_t)N * 2 + 1) * sizeof(int)));
+    unsigned long long* mail = reinterpret_cast<unsigned long long*>(take(pd_mail_bytes(N, T, U)));
+    if (w) *w = Workspace{alphas, betas, ws2, ll, mismatch, redo, mail};
     return off;
 }
 
@@ -130,7 +132,7 @@ rnntStatus_t rnnt_amd_loss(rnntStream_t stream, void* workspace, int input_kind,
     if (e != hipSuccess) return RNNT_STATUS_PROLOGUE_FAILED;
 
     // 2. alpha / beta sweeps (2N workgroups, concurrent)
-    LatticeArgs la{w.ws2, nullptr, xn, yn, w.alphas, w.betas, w.ll, T, U, 2, 0, nullptr, w.redo};
+    LatticeArgs la{w.ws2, nullptr, xn, yn, w.alphas, w.betas, w.ll, T, U, 2, 0, nullptr, w.redo, w.redo + 2 * N, w.mail};
     if (launch_lattice(stream, la, N, LOAD_SKEWED) != hipSuccess) return RNNT_STATUS_WARP_FAILED;
 
     // 3. gradients + costs (+ guard).  For a dense result the pairs are produced in place in the
@@ -157,15 +159,14 @@ rnntStatus_t rnnt_amd_debug_lattice_only(rnntStream_t stream, void* workspace, c
     if (!dims_ok(N, T, U) || !workspace) return RNNT_STATUS_INVALID_ARGUMENT;
     Workspace w;
     carve(workspace, N, T, U, &w);
-    LatticeArgs la{w.ws2, nullptr, xn, yn, w.alphas, w.betas, w.ll, T, U, 2, 0, nullptr, w.redo};
+    LatticeArgs la{w.ws2, nullptr, xn, yn, w.alphas, w.betas, w.ll, T, U, 2, 0, nullptr, w.redo, w.redo + 2 * N, w.mail};
     if (launch_lattice(stream, la, N, LOAD_SKEWED) != hipSuccess) return RNNT_STATUS_WARP_FAILED;
     return RNNT_STATUS_SUCCESS;
 }
 
 size_t rnnt_amd_workspace_size_compact(int N, int64_t STU) {
     if (N < 0 || N > 65535 || STU < 0 || STU >= ((int64_t)1 << 32)) return 0;
-    return align_up((size_t)STU * 4) * 2 + align_up((size_t)STU * 8) + align_up((size_t)N * 4) * 2 +
-           align_up((size_t)N * 8) + ALIGN;
+    return align_up((size_t)STU * 4) * 2 + align_up((size_t)STU * 8) + align_up((size_t)N * 4) * 2 + ALIGN;
 }
 
 // Device-side preparation of a compact batch (offsets + launch bounds), one launch.
@@ -196,12 +197,11 @@ rnntStatus_t rnnt_amd_loss_compact(rnntStream_t stream, void* workspace, const f
     float* betas = reinterpret_cast<float*>(p); p += align_up((size_t)STU * 4);
     float* ws2 = reinterpret_cast<float*>(p); p += align_up((size_t)STU * 8);
     float* ll = reinterpret_cast<float*>(p); p += align_up((size_t)N * 4);
-    int* mismatch = reinterpret_cast<int*>(p); p += align_up((size_t)N * 4);
-    int* redo = reinterpret_cast<int*>(p);
+    int* mismatch = reinterpret_cast<int*>(p);
     if (launch_gather_compact(stream, xs, ys, xn, yn, cell_offsets, label_offsets, ws2, loc, N, Tmax, Umax, V,
                               blank) != hipSuccess)
         return RNNT_STATUS_PROLOGUE_FAILED;
-    LatticeArgs la{ws2, nullptr, xn, yn, alphas, betas, ll, Tmax, Umax, 2, 0, cell_offsets, redo};
+    LatticeArgs la{ws2, nullptr, xn, yn, alphas, betas, ll, Tmax, Umax, 2, 0, cell_offsets};
     if (launch_lattice(stream, la, N, LOAD_SKEWED) != hipSuccess) return RNNT_STATUS_WARP_FAILED;
     GradArgs ga{ws2, nullptr, xn, yn, alphas, betas, ll, grads2 ? grads2 : ws2, costs, mismatch,
                 Tmax, Umax, 2, 0, fastemit_lambda, cell_offsets};

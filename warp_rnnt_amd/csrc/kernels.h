@@ -16,9 +16,13 @@ struct LatticeArgs {
     int T, U, V, blank;   // V/blank: LOAD_DENSE only
     const int64_t* offs;  // compact layout: (N+1,) cell offset of each utterance's (T_n, U_n) plane;
                           // nullptr = padded (N,T,U) planes
-    int* redo;            // (2N,) [2n+dir]: written by the probability-domain kernel (1 = inputs outside the range
-                          // it can represent), read by the log-domain kernel launched behind it (0 = nothing to do);
-                          // nullptr = log-domain kernel only
+    int* redo;            // (2N,) [2n+dir]: written by the probability-domain kernel (non-zero = inputs outside the
+                          // range it can represent, or a lost hand-over), read by the log-domain kernel launched
+                          // behind it (0 = nothing to do); nullptr = log-domain kernel only
+    int* queue;           // work-item counter of the probability-domain kernel; MUST be redo + 2N (zeroed together)
+    unsigned long long* mail;  // its hand-over rings between column blocks (pd_mail_bytes), needed when U > 64
+    int mail_blocks;      // filled in by launch_lattice_pd
+    unsigned epoch;       // filled in by launch_lattice_pd
 };
 
 struct GradArgs {
@@ -41,8 +45,10 @@ hipError_t launch_lattice(hipStream_t stream, const LatticeArgs& a, int N, int l
 // wave-specialised log-domain variant (diagonal-major loader only); hipErrorNotSupported when U > 512.
 // With a.redo set only the (utterance, direction) pairs flagged there are swept.
 hipError_t launch_lattice_ws(hipStream_t stream, const LatticeArgs& a, int N);
-// probability-domain variant (lattice_pd.hip; diagonal-major loader, needs a.redo); hipErrorNotSupported when U > 320
+// probability-domain variant (lattice_pd.hip; diagonal-major loader; needs a.redo, a.queue and -- for U > 64 --
+// a.mail of pd_mail_bytes(N,T,U) bytes); hipErrorNotSupported when they are missing
 hipError_t launch_lattice_pd(hipStream_t stream, const LatticeArgs& a, int N);
+size_t pd_mail_bytes(int N, int T, int U);
 hipError_t launch_grads(hipStream_t stream, const GradArgs& a, int N, int loader, int writer);
 
 // prologue / epilogue streaming kernels

@@ -446,11 +446,20 @@ hipError_t launch_lattice(hipStream_t stream, const LatticeArgs& a, int N, int l
 #ifndef RNNT_LATTICE_LEGACY
     if (loader == LOAD_SKEWED) {
 #ifndef RNNT_LATTICE_LOGDOMAIN
-        // preferred: probability-domain sweep (lattice_pd.hip, U <= 320), followed by the log-domain kernel for
-        // the (utterance, direction) pairs whose inputs it flagged -- normally none: those workgroups return
-        // at once
-        static const bool pd_off = getenv("RNNT_LATTICE_LOGDOMAIN") != nullptr;   // A/B switch, read once
-        if (a.redo && !pd_off) {
+        // Long lattices of small batches: probability-domain sweep, one workgroup per 64-column block
+        // (lattice_pd.hip), followed by the log-domain kernel for the (utterance, direction) pairs whose inputs it
+        // flagged -- normally none: those workgroups return at once.  Where it pays, measured on MI355X
+        // (tools/lattice_probe.py, T=1500): its column blocks want a CU each, so up to ~320 workgroups
+        // (N <= 32 at U=300: 145-160 us against 168 us; N=48: 204 against 184), and its fixed costs (a memset node,
+        // a second launch, the hand-over lag between column blocks) are only recovered on long sweeps
+        // (T=400,U=100: 47 against 42 us; T=1500,U=64: 79 against 95 us).  U <= 512 because the log-domain kernel
+        // behind it must be able to redo a sweep.  RNNT_LATTICE=logdomain|pd overrides the choice (A/B runs).
+        static const char* force = getenv("RNNT_LATTICE");
+        const int nA = (a.U + WAVE - 1) / WAVE;
+        bool use_pd = a.redo && a.queue && !a.offs && nA <= 8 && (long long)2 * N * nA <= 320 && a.T + a.U >= 1024;
+        if (force && force[0] == 'l') use_pd = false;
+        if (force && force[0] == 'p') use_pd = a.redo && a.queue && !a.offs && nA <= 8;
+        if (use_pd) {
             const hipError_t e = launch_lattice_pd(stream, a, N);
             if (e == hipSuccess) return launch_lattice_ws(stream, a, N);
             if (e != hipErrorNotSupported) return e;

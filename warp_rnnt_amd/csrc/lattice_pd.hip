@@ -1,37 +1,55 @@
-// Probability-domain alpha / beta lattice sweep for MI355X (gfx950), diagonal-major layout.
+// Probability-domain alpha / beta lattice sweep for MI355X (gfx950), diagonal-major layout,
+// one workgroup (three waves) per 64-column block of a sweep.
 //
-// Same anti-diagonal schedule as lattice_ws.hip (read its header first: lanes are lattice columns, a
-// column block of 64 runs one block of K=8 diagonals behind its left neighbour, one s_barrier per block,
-// the boundary column is handed over through LDS).  What changes is the ARITHMETIC of the serial chain.
-// The log-domain step  lse(a,b) = max + log1p(exp(-|a-b|))  costs the computing wave 16 instructions per
-// diagonal (sub, mul, v_exp_f32, add, v_log_f32, three for the rounding correction, max, adds, DPP ...),
-// and a lone wave issues one instruction every ~5 cycles whatever it is -- the sweep is bound by that
-// count.  Here the recurrence runs on PROBABILITIES with a per-column binary exponent:
+// Same anti-diagonal schedule as lattice_ws.hip (read its header first: lanes are lattice columns, a column
+// block of 64 runs behind its left neighbour, blocks of K=8 diagonals, one s_barrier per block).  Two
+// things change.
 //
-//     true alpha of column u on the current diagonal = A[u] * 2^E[u]          A fp64, E int32
-//     per diagonal      val = fma(A_left, 2^(E_left - E_own), Y)              the factor is exact
-//                       Y   = val * pB(cell)      X = val * pL(cell)           (beta: mirrored lattice, weights of
-//                                                                               the receiving cell, see step())
-//     every K diagonals Y and X are rescaled by the exponent of Y (exact) and E takes it up
+// 1. The ARITHMETIC of the serial chain.  The log-domain step lse(a,b) = max + log1p(exp(-|a-b|)) costs the
+//    computing wave ~19 instructions per diagonal and a lone wave issues one instruction every ~6.5 cycles
+//    (tools/ubench/pd_steps.hip: 65 cycles per step).  Here the recurrence runs on PROBABILITIES with a
+//    per-column binary exponent:
+//        true alpha of column u on the current diagonal = A[u] * 2^E[u]          A fp64, E int32
+//        per diagonal      val = fma(A_left, 2^(E_left - E_own), Y)              the factor is exact
+//                          Y   = val * pB(cell)      X = val * pL(cell)           (beta: mirrored lattice, the
+//                                                                                  weights of the receiving cell)
+//        every K diagonals Y and X are rescaled by the exponent of Y (exact) and E takes it up
+//    = two 32-bit DPP moves and three or four fp64 operations per diagonal (27 cycles per step in the same
+//    micro-benchmark; fp64 VALU issues at the fp32 rate on this chip).  fp64 state because its exponent range
+//    (2^+-1022) cannot be left within K steps of fp32-representable probabilities (>= 2^-126 each): no range
+//    bookkeeping inside the chain, and columns may differ by hundreds of binary orders of magnitude (they do:
+//    tests/pd_model.py, tests/test_pd_model.py).  The conversions live on two helper waves, off the chain:
+//      LOADER  HBM -> registers -> p = exp2(lp*log2e) (v_mul_f32, v_exp_f32, v_cvt_f64_f32) -> LDS, two blocks
+//              ahead; also the input check: a probability that leaves [2^-115, 2^100] (log-prob below -80, -inf,
+//              or far above 0) cannot be carried as an fp32 -- the (utterance, direction) is then redone by the
+//              log-domain kernel (lattice_ws.hip, launched behind this one; it returns at once otherwise);
+//      STORER  LDS -> ln2*(log2(mantissa) + exponent) -> HBM, one block behind: the top 24 significant bits of
+//              the fp64 value relabelled as an fp32 in [1,2) (v_alignbit_b32, v_and_or_b32), v_log_f32, one
+//              multiply + one fma: the stored alpha/beta carry <= 0.5 ulp of rounding plus 2^-23 relative --
+//              nothing accumulates along the sweep (the log-domain chain rounds at |alpha| ~ 6e3 every step:
+//              1e-2 on the gradients at T=1500,U=300, against 8e-4 here).
+//    tests/pd_model.py is the executable statement of this arithmetic (checked on the CPU against fp64).
 //
-//   = two 32-bit DPP moves and four fp64 operations per diagonal.  fp64 state because its exponent range
-//   (2^+-1022) cannot be left within K steps of fp32-representable probabilities (>= 2^-126 each): no range
-//   bookkeeping inside the chain, and columns may differ by hundreds of binary orders of magnitude (they do:
-//   tests/pd_model.py).  The conversions live on two helper waves per column block, off the chain:
-//     LOADER  HBM -> registers -> p = exp2(lp*log2e) (v_mul_f32, v_exp_f32, v_cvt_f64_f32) -> LDS, two blocks
-//             ahead; also the input check: a log-prob outside [-80, 80] (or -inf) cannot be represented as
-//             an fp32 probability -- the whole (utterance, direction) is then redone by the log-domain kernel
-//             (lattice_ws.hip, launched behind this one; it returns at once when no flag is set);
-//     STORER  LDS -> ln2*(log2(mantissa) + exponent) -> HBM, one block behind: the top 24 significant bits of
-//             the fp64 value relabelled as an fp32 in [1,2) (v_alignbit_b32, v_bfi_b32), v_log_f32, and one
-//             multiply + one fma: the stored alpha/beta carry <= 0.5 ulp of rounding plus 2^-23 relative --
-//             no error accumulates along the sweep (the log-domain chain rounds at |alpha| ~ 6e3 every step:
-//             1e-2 on the gradients at T=1500,U=300, against 8e-4 here; tests/test_pd_model.py).
-//   tests/pd_model.py is the executable statement of this arithmetic (checked on the CPU against fp64).
+// 2. WHERE the column blocks run.  With all column blocks of a sweep in one workgroup (lattice_ws.hip) a
+//    U=300 sweep puts ten waves on the four SIMDs of one CU and the CU's issue rate becomes the limit (95 us at
+//    U=64, 166 us at U=300 for T=1500) while seven eighths of the chip idle at N=16.  Here every column block
+//    is its own workgroup, wherever the dispatcher puts it; the boundary column travels through L2:
+//      * the producer's storer wave publishes, per block, 17 self-validating 8-byte granules {32 data bits,
+//        32-bit tag = launch epoch ^ hash(block)} with one agent-scope (sc1) store instruction;
+//      * the consumer's loader wave requests them two blocks ahead with agent-scope loads (its HBM prefetch
+//        queue), checks the tags when it needs the block and re-polls only while the producer is not there
+//        yet -- so the consumer settles a few microseconds behind the producer and the hand-over costs
+//        nothing per block; there is no flag, no fence, no back-pressure (the ring is as long as the sweep);
+//      * work items (column block, sweep) are handed out by an atomic counter in column-block-major order:
+//        whoever holds item i knows every item < i has been taken by a workgroup that is running or done, so
+//        a consumer never waits for a producer that has not been scheduled (no assumption about dispatch order);
+//      * every wait is bounded; a timeout flags the sweep for the log-domain kernel instead of hanging.
 //
 // Reference counterpart: core_gather.cu:37-133 (alphas), :135-234 (betas) -- 32x1 warp tiles ordered by
 // global spin locks, lse per cell.  Outputs are the same quantities (log alpha, log beta, fp32).
 #include <atomic>
+#include <cstdlib>
+#include <random>
 #include <type_traits>
 
 #include "common.h"
@@ -42,33 +60,40 @@ namespace rnnt {
 namespace pd {
 
 constexpr int K = 8;             // diagonals per block (= renormalisation interval)
-constexpr int MAXA = 5;          // column blocks per workgroup: 3 waves each -> 15 waves, 320 columns per pass
+constexpr int KH = K / 2;        // diagonals per block and helper wave
 constexpr int PSLOTS = 2;        // LDS ring of probability blocks
 constexpr int VSLOTS = 2;        // LDS ring of value blocks
-constexpr int MSLOTS = 2;        // LDS ring of boundary-column blocks
+constexpr int MSLOTS = 2;        // LDS rings of boundary-column blocks (incoming and outgoing)
 constexpr int DLOAD = 2;         // the loader issues its HBM loads this many blocks before it converts them
 constexpr int NBR = DLOAD + 1;   // its register ring
-constexpr int SHIFT = DLOAD;     // global block g = local time + idx + SHIFT, so the first load is at g >= 0
 constexpr int PSTRIDE = 36;      // dwords per lane per probability slot: 8 cells x (pB,pL) fp64 = 32, +4: the
                                  // 16-lane groups of ds_read/write_b128 then cover all 64 banks (MI355X_MICROARCH.md)
 constexpr int VSTRIDE = 20;      // dwords per lane per value slot: 8 fp64 = 16, +4 (same reason)
+constexpr int GRAN = 17;         // granules per block: 16 dwords of lane 63's X on entry to the 8 steps + its exponent
+constexpr int GPITCH = 32;       // granules reserved per block in the global ring (256 bytes)
 constexpr int RSRC_WORD3 = 0x00020000;
 constexpr int OOB = (int)0x80000000;
-constexpr float LP_ABS_MAX = 80.0f;   // |log-prob| beyond this: exp() leaves fp32 -> log-domain kernel
+constexpr float P_MIN = 0x1p-115f, P_MAX = 0x1p100f;   // accepted range of an fp32 probability (see header)
 constexpr float LOG2E = 1.44269504088896340736f;
 constexpr float LN2 = 0.693147180559945309417f;
+constexpr int SPIN_LIMIT = 1 << 21;                      // polls before a hand-over is declared lost
+#ifndef RNNT_PD_LAG
+#define RNNT_PD_LAG 3
+#endif
+constexpr int LAG = RNNT_PD_LAG; // blocks a column block lets its left neighbour get ahead when it has caught up with it
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef double f64x2 __attribute__((ext_vector_type(2)));
+typedef unsigned long long u64;
 
-struct alignas(16) Smem {   // per column block
+struct alignas(16) Smem {
     float probs[PSLOTS][WAVE * PSTRIDE];    // [lane][k] (pB, pL) fp64
     float vals[VSLOTS][WAVE * VSTRIDE];     // [lane][k] fp64 value, scale 2^exps[lane]
     int exps[VSLOTS][WAVE];
-    double mailx[MSLOTS][K];                // lane 63's X on entry to step k of the block
-    double zeros[K];                        // what every lane but lane 0 reads instead of the mailbox
-    int maile[MSLOTS][4];                   // [0]: lane 63's exponent of that block
+    unsigned mail_in[MSLOTS][GPITCH];       // left neighbour's boundary column, as its granule payloads
+    unsigned mail_out[MSLOTS][GPITCH];      // this block's boundary column: [0,16) X, [16] exponent
+    double zeros[K];                        // what every lane but lane 0 reads instead of mail_in
     double dumpx[WAVE][2];                  // where the other 63 lanes put their copy of the boundary column
     int dumpe[WAVE];
 };
@@ -81,15 +106,17 @@ __device__ __forceinline__ void block_barrier() {
 
 // Lane i receives src from lane i-1; lane 0 receives 0.  Two v_mov_b32_dpp wave_shr:1 bound_ctrl:1.
 __device__ __forceinline__ double wave_shr1_f64(double src) {
-    const unsigned long long b = __builtin_bit_cast(unsigned long long, src);
+    const u64 b = __builtin_bit_cast(u64, src);
     const int lo = __builtin_amdgcn_mov_dpp((int)b, 0x138, 0xf, 0xf, true);
     const int hi = __builtin_amdgcn_mov_dpp((int)(b >> 32), 0x138, 0xf, 0xf, true);
-    return __builtin_bit_cast(double, ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
+    return __builtin_bit_cast(double, ((u64)(unsigned)hi << 32) | (unsigned)lo);
 }
 // Lane i receives src from lane i-1; lane 0 receives `first`.
 __device__ __forceinline__ int wave_shr1_i32(int first, int src) {
     return __builtin_amdgcn_update_dpp(first, src, 0x138, 0xf, 0xf, false);
 }
+
+__device__ __forceinline__ unsigned block_tag(unsigned epoch, int lb) { return epoch ^ ((unsigned)(lb + 1) * 0x9E3779B1u); }
 
 struct Cell2 { double b, l; };   // blank / label probability of one lattice cell
 
@@ -99,11 +126,12 @@ struct Cell2 { double b, l; };   // blank / label probability of one lattice cel
 //           started follows the last started lane)
 //   MAIL:   lane 63's X on entry to every step is recorded for the right neighbour
 template <bool BETA, bool MASKED, bool SEED, bool MAIL>
-__device__ __forceinline__ void compute_block(const Cell2 (&cur)[K], Cell2 (&nxt)[K], const double (&seed)[K], const int e_mail,
-                                              double& Y, double& X, int& E, const int d0, const int ucol_chk,
-                                              const int Tn, const int front, const bool started_all,
-                                              const bool lane_started, const float* next_probs, float* vdst,
-                                              double* xdst, int* edst, int* email_dst) {
+__device__ __forceinline__ void compute_block(const Cell2 (&cur)[K], Cell2 (&nxt)[K], const double (&seed)[K],
+                                              const int e_mail, double& Y, double& X, int& E, const int d0,
+                                              const int ucol_chk, const int Tn, const int front,
+                                              const bool started_all, const bool lane_started,
+                                              const float* next_probs, float* vdst, double* xdst, int* edst,
+                                              int* email_dst) {
     // ---- renormalisation (exact: powers of two) ----
     const int e = __builtin_amdgcn_frexp_exp(Y);          // 0 for Y == 0
     Y = __builtin_amdgcn_frexp_mant(Y);
@@ -168,16 +196,27 @@ __device__ __forceinline__ void compute_block(const Cell2 (&cur)[K], Cell2 (&nxt
     }
 }
 
-template <bool BETA, bool COMPACT>
-__device__ __forceinline__ void sweep(const LatticeArgs& a, const int n, Smem* smem, int* wg_bad) {
-    const UttLens len = utt_lens<COMPACT>(a.xn, a.yn, n, a.T, a.U);
-    if (COMPACT && !len.ok) return;   // no plane of its own to sweep (uniform over the workgroup, before any barrier)
+struct Item { int n, dir, cb; };
+
+// HAS_LEFT / HAS_RIGHT are template parameters so that the helper waves' steady-state loops contain no
+// data-dependent branch around their memory instructions: with one, the compiler's s_waitcnt bookkeeping falls
+// back to vmcnt(0) at the join and every block pays a full HBM round trip (measured: 1.3 us instead of 0.45 us
+// per block).
+template <bool BETA, bool COMPACT, bool HAS_LEFT, bool HAS_RIGHT>
+__device__ __forceinline__ void sweep(const LatticeArgs& a, const Item it, const UttLens len, const int nA, Smem& sm,
+                                      int* wg_bad) {
+    const int n = it.n, idx = it.cb;
     const int Tn = len.Tn, Un = len.Un;
     const int T = COMPACT ? Tn : a.T, U = COMPACT ? Un : a.U;
     const int lane = threadIdx.x & (WAVE - 1);
-    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    if (Un == 1) {   // no labels: prefix / suffix sums by one wave (uniform over the workgroup, no barrier yet)
-        if (w == 0) {
+    // five waves: 0 computes; 1,2 load (diagonals 0-3 / 4-7 of every block); 3,4 store (same split).  The conversions
+    // cost a helper wave about as many instructions per diagonal as the chain costs the compute wave; two helpers of
+    // each kind keep them off the critical path
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int role = wv == 0 ? 0 : (wv <= 2 ? 1 : 2);   // 0 compute, 1 loader, 2 storer
+    const int half_rt = (wv - 1) & 1;                   // which four diagonals of a block a helper wave handles
+    if (Un == 1) {   // no labels: prefix / suffix sums by one wave of the first column block's workgroup
+        if (idx == 0 && role == 0) {
             const size_t nb1 = COMPACT ? (size_t)a.offs[n] : (size_t)n * T * U;
             const float2* lp2 = reinterpret_cast<const float2*>(a.lp) + nb1;
             const float total = single_column_scan<BETA>(Tn, (BETA ? a.betas : a.alphas) + nb1, U, lane,
@@ -186,95 +225,164 @@ __device__ __forceinline__ void sweep(const LatticeArgs& a, const int n, Smem* s
         }
         return;
     }
-    const int nA = blockDim.x / (3 * WAVE);           // column blocks
-    const int role = w / nA;                          // 0 compute, 1 loader, 2 storer
-    const int idx = w - role * nA;                    // column block
     const size_t nbase = COMPACT ? (size_t)a.offs[n] : (size_t)n * T * U;
     float* out = (BETA ? a.betas : a.alphas) + nbase;
     const int ndiag = Tn + Un - 1;
-    Smem& sm = smem[idx];
 
-    const int ucol = WAVE * idx + lane;               // column in sweep coordinates (one pass: Un <= 64*nA)
+    const int wave_c = WAVE * idx;                    // first sweep column of this column block
+    const int ucol = wave_c + lane;                   // column in sweep coordinates
     const bool colvalid = ucol < Un;
     const int u = BETA ? (Un - 1 - ucol) : ucol;
     const int uc = min(max(u, 0), U - 1);
     const int ucol_chk = colvalid ? ucol : 0x40000000;
-    const int nwa = min(nA, (Un + WAVE - 1) / WAVE);  // column blocks with a live column
-    const int wave_c = WAVE * idx;
+    const int nwa = (Un + WAVE - 1) / WAVE;           // column blocks with a live column
     const int lo = wave_c / K;
     const int hi = (min(ndiag, Tn + wave_c + WAVE) + K - 1) / K;
-    const bool live_blk = (idx < nwa) && (lo < hi);
-    const int hi_last = (min(ndiag, Tn + WAVE * (nwa - 1) + WAVE) + K - 1) / K;
-    const int G = hi_last + (nwa - 1) + 3 + SHIFT;    // barriers every wave executes
-    // every lane live for the whole block?  (all started, none finished, all 64 columns inside the lattice)
+    if (idx >= nwa || lo >= hi) return;               // nothing to sweep here (uniform)
+    constexpr bool has_left = HAS_LEFT, has_right = HAS_RIGHT;
+    // blocks for which the left neighbour publishes its boundary column
+    const int hi_left = has_left ? (min(ndiag, Tn + wave_c) + K - 1) / K : 0;
+    const int G = (hi - lo) + 3 + DLOAD;              // barriers every wave executes
+    // Every lane that owns a lattice column live for the whole block?  (all of them started, none finished.)  Lanes
+    // beyond the last column (the last column block of a lattice whose width is not a multiple of 64) then run the
+    // unpredicated code too: they read an in-range cell, their values are garbage that only travels to the right
+    // -- to other such lanes --, their stores are dropped by the buffer bounds check (voffset = OOB) and the input
+    // check ignores them.  Without this the last column block would run the predicated paths for the whole sweep
+    // and, being the slowest link of the chain, set the pace (T=1500: 305 us at U=300 against 130 us at U=128).
+    const int last_col = min(wave_c + WAVE - 1, Un - 1);
     auto full_block = [&](const int lb) {
         const int d0 = lb * K;
-        return (d0 >= wave_c + WAVE - 1) && (d0 + K <= wave_c + Tn) && (wave_c + WAVE <= Un);
+        return (d0 >= last_col) && (d0 + K <= wave_c + Tn);
     };
+    // hand-over rings in global memory: one per (sweep, column-block boundary)
+    const size_t sweep_id = (size_t)2 * n + (BETA ? 1 : 0);
+    u64* ring_in = has_left ? a.mail + ((sweep_id * (nA - 1) + (idx - 1)) * (size_t)a.mail_blocks) * GPITCH : nullptr;
+    u64* ring_out = has_right ? a.mail + ((sweep_id * (nA - 1) + idx) * (size_t)a.mail_blocks) * GPITCH : nullptr;
 
-    if (!live_blk) {
-        for (int g = 0; g < G; ++g) block_barrier();
-        return;
-    }
     const int rowb_lp = U * 8, rowb_out = U * 4;
-    // row (forward diagonal mod T) of the first diagonal of block `lo`, and how rows advance
+    // row (forward diagonal mod T) of the first diagonal of block `lo`; rows advance by one per diagonal
+    // (alpha upwards, beta downwards) and wrap modulo T
     const int dF0 = BETA ? (ndiag - 1 - lo * K) : lo * K;
     const int row0 = ((dF0 % T) + T) % T;
-    auto advance = [&](int& row, int (&rows)[K]) {
+    // byte offsets of the K rows of the next block, rowb bytes per row; `row` moves on by K
+    auto advance = [&](int& row, const int rowb, int (&offs)[K]) {
+        const bool nowrap = BETA ? (row >= K - 1) : (row + K <= T);
+        if (nowrap) {                                   // the common case: one multiply, K-1 adds
+            const int base = row * rowb;
 #pragma unroll
-        for (int k = 0; k < K; ++k) {
-            rows[k] = row;
-            row = BETA ? (row == 0 ? T - 1 : row - 1) : (row + 1 == T ? 0 : row + 1);
+            for (int k = 0; k < K; ++k) offs[k] = BETA ? base - k * rowb : base + k * rowb;
+            row = BETA ? row - K : row + K;
+            if (BETA) { if (row < 0) row += T; } else { if (row >= T) row -= T; }
+        } else {
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                offs[k] = row * rowb;
+                row = BETA ? (row == 0 ? T - 1 : row - 1) : (row + 1 == T ? 0 : row + 1);
+            }
         }
     };
 
-    if (role == 1) {
+    // the helper waves' bodies are generic over which half of a block they handle (compile time: no data-dependent
+    // branch in their steady-state loops)
+    auto loader = [&](auto half_c) {
+        constexpr int half = decltype(half_c)::value;
+        constexpr int k0 = half * KH;
         // ------------------------------ loader ------------------------------
         const __amdgpu_buffer_rsrc_t rs_lp = __builtin_amdgcn_make_buffer_rsrc(
             const_cast<float*>(a.lp) + nbase * 2, 0, T * U * 8, RSRC_WORD3);
-        f32x2 regs[NBR][K];
+        f32x2 regs[NBR][KH];
+        u64 mregs[NBR] = {0, 0, 0};
+        constexpr bool does_mail = has_left && half == 0;  // the first loader wave also fetches the boundary column
         int row_ld = row0;
-        float amax = 0.0f;                            // max |log-prob| over the live cells this wave converted
-        auto load_block = [&](f32x2 (&dst)[K]) {
-            int rows[K];
-            advance(row_ld, rows);
+        float pmin = 1.0f, pmax = 1.0f;               // range of the probabilities of live cells this wave produced
+        const u64* gsrc = has_left ? ring_in + (lane < GRAN ? lane : GRAN) : nullptr;   // lanes >= 17: a pad granule
+        (void)gsrc; (void)mregs;
+        auto load_block = [&](f32x2 (&dst)[KH]) {
+            int offs[K];
+            advance(row_ld, rowb_lp, offs);
 #pragma unroll
-            for (int k = 0; k < K; ++k) {
+            for (int k = 0; k < KH; ++k) {
+                const int off = half ? offs[k + KH] : offs[k];
 #ifdef RNNT_PD_NOLOAD      // timing probe: no HBM reads
-                dst[k] = f32x2{-1.5f - 0.001f * (float)(rows[k] & 7), -2.5f};
+                dst[k] = f32x2{-1.5f - 0.001f * (float)(off & 7), -2.5f};
 #else
-                dst[k] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rs_lp, uc * 8, rows[k] * rowb_lp, 0));
+                dst[k] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rs_lp, uc * 8, off, 0));
 #endif
             }
         };
-        // local time p: converts pairs(p) (loaded at p-DLOAD) into LDS, then issues the loads of pairs(p+DLOAD)
+        // the left neighbour's boundary column of block lb: requested two blocks ahead, checked when needed
+        auto mail_request = [&](const int lb) {
+            return __hip_atomic_load(gsrc + (size_t)lb * GPITCH, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        };
+        auto mail_valid = [&](const int lb, const u64 g) {
+            const bool ok = lane >= GRAN || (unsigned)(g >> 32) == block_tag(a.epoch, lb);
+            return __builtin_amdgcn_ballot_w64(!ok) == 0;
+        };
+        auto mail_wait = [&](const int lb) {               // poll until block lb of the neighbour is there
+            for (int spins = 0;; ++spins) {
+                const u64 g = mail_request(lb);
+                if (mail_valid(lb, g)) return g;
+                if (spins > SPIN_LIMIT) { *wg_bad = 2; return g; }   // producer lost: the log-domain kernel redoes the sweep
+                __builtin_amdgcn_s_sleep(8);
+            }
+        };
+        auto mail_stage = [&](const int lb, u64 g) {
+            if (!mail_valid(lb, g)) {
+                // The request was issued two blocks ago and the producer had not got there yet: this column
+                // block has caught up with its neighbour.  Let the neighbour get LAG blocks ahead (or finish)
+                // before going on, so that the look-ahead requests of the following blocks find their data --
+                // otherwise every block would pay a polling round trip (~1.3 us against ~0.4 us of work).
+                mail_wait(min(lb + LAG, hi_left - 1));
+                g = mail_wait(lb);
+            }
+            if (lane < GRAN) sm.mail_in[lb & (MSLOTS - 1)][lane] = (unsigned)g;
+        };
+        // local time p: converts pairs(p) (loaded at p-DLOAD) into LDS and stages the neighbour's block p-1,
+        // then issues the loads of pairs(p+DLOAD) and the request for the neighbour's block p+1
         auto l_step = [&](const int p, auto ph, auto guarded) {
             constexpr int PH = decltype(ph)::value;           // p mod NBR
             constexpr bool GUARDED = decltype(guarded)::value;
             if (!GUARDED || (p >= lo && p < hi)) {
-                float* dst = &sm.probs[p & (PSLOTS - 1)][lane * PSTRIDE];
+                float* dst = &sm.probs[p & (PSLOTS - 1)][lane * PSTRIDE + 4 * k0];
                 const bool full = !GUARDED || full_block(p);
-                const int d0 = p * K;
+                const int d0 = p * K + k0;
 #pragma unroll
-                for (int k = 0; k < K; ++k) {
+                for (int k = 0; k < KH; ++k) {
                     const f32x2 v = regs[PH][k];
-                    const float m = __builtin_fmaxf(__builtin_fabsf(v.x), __builtin_fabsf(v.y));
+#ifdef RNNT_PD_NOCONV      // timing probe: helper waves without their arithmetic
+                    const float pb = __builtin_fmaf(v.x, 0.001f, 0.5f), pl = __builtin_fmaf(v.y, 0.001f, 0.25f);
+#else
+                    const float pb = __builtin_amdgcn_exp2f(v.x * LOG2E);
+                    const float pl = __builtin_amdgcn_exp2f(v.y * LOG2E);
+#endif
                     if (full) {
-                        amax = __builtin_fmaxf(amax, m);
+                        asm("v_min3_f32 %0, %0, %1, %2" : "+v"(pmin) : "v"(pb), "v"(pl));
+                        asm("v_max3_f32 %0, %0, %1, %2" : "+v"(pmax) : "v"(pb), "v"(pl));
                     } else {
-                        // cells outside the utterance may hold anything: they are never used, never judged.
-                        // the label channel of the last column is not part of the lattice either
+                        // cells outside the utterance may hold anything: they are never used, never judged;
+                        // nor is the label channel of the last column
                         const bool live = (unsigned)(d0 + k - ucol_chk) < (unsigned)Tn;
-                        const float mm = (u == Un - 1) ? __builtin_fabsf(v.x) : m;
-                        amax = live ? __builtin_fmaxf(amax, mm) : amax;
+                        const float pl_j = (u == Un - 1) ? pb : pl;
+                        if (live) {
+                            pmin = __builtin_fminf(pmin, __builtin_fminf(pb, pl_j));
+                            pmax = __builtin_fmaxf(pmax, __builtin_fmaxf(pb, pl_j));
+                            if (!(pb == pb) || !(pl_j == pl_j)) pmax = __builtin_inff();   // NaN in a live cell
+                        }
                     }
                     f64x2 pr;
-                    pr.x = (double)__builtin_amdgcn_exp2f(v.x * LOG2E);
-                    pr.y = (double)__builtin_amdgcn_exp2f(v.y * LOG2E);
+#ifdef RNNT_PD_NOCONV
+                    pr.x = __builtin_bit_cast(double, ((u64)__builtin_bit_cast(unsigned, pb) << 29) | 0x3fd0000000000000ull);
+                    pr.y = __builtin_bit_cast(double, ((u64)__builtin_bit_cast(unsigned, pl) << 29) | 0x3fc0000000000000ull);
+#else
+                    pr.x = (double)pb;
+                    pr.y = (double)pl;
+#endif
                     *reinterpret_cast<f64x2*>(dst + 4 * k) = pr;
                 }
             }
+            if constexpr (does_mail) { if (!GUARDED || (p - 1 >= lo && p - 1 < hi_left)) mail_stage(p - 1, mregs[PH]); }
             if (!GUARDED || (p + DLOAD >= lo && p + DLOAD < hi)) load_block(regs[(PH + DLOAD) % NBR]);
+            if constexpr (does_mail) { if (!GUARDED || (p + 1 >= lo && p + 1 < hi_left)) mregs[(PH + DLOAD) % NBR] = mail_request(p + 1); }
             block_barrier();
         };
         auto l_any = [&](const int p, auto guarded) {
@@ -283,16 +391,13 @@ __device__ __forceinline__ void sweep(const LatticeArgs& a, const int n, Smem* s
             else if (m == 1) l_step(p, std::integral_constant<int, 1>{}, guarded);
             else l_step(p, std::integral_constant<int, 2>{}, guarded);
         };
-        const int p_first = lo - DLOAD;
-        int g = 0;
-        for (; g < p_first + idx + SHIFT; ++g) block_barrier();
-        int p = p_first;
-        const int p_end = hi;                              // last conversion at p = hi-1
+        int p = lo - DLOAD;                                // interval index = p - (lo - DLOAD)
+        const int p_end = hi + 1;                          // last conversion at hi-1, last staging (block hi-1) at hi
         // steady range: both activities live and every lane live (no predicates), p = 0 (mod NBR) at its start
-        int ps0 = max(lo, (wave_c + WAVE - 1 + K - 1) / K);
+        int ps0 = max(lo + 1, (last_col + K - 1) / K);     // (lo + 1: the neighbour's block p-1 >= lo)
         ps0 += (NBR - ((ps0 % NBR) + NBR) % NBR) % NBR;
         int ps1 = min(hi - DLOAD, (wave_c + Tn) / K);      // exclusive: blocks [.., ps1) are full
-        if (wave_c + WAVE > Un) ps1 = p_first;             // a column block with columns outside the lattice is never "full"
+        if (has_left) ps1 = min(ps1, hi_left - 1);         // and the neighbour's block p+1 < hi_left
         for (; p < p_end && p < ps0; ++p) l_any(p, std::true_type{});
         for (; p + NBR <= ps1; p += NBR) {
             l_step(p, std::integral_constant<int, 0>{}, std::false_type{});
@@ -301,30 +406,41 @@ __device__ __forceinline__ void sweep(const LatticeArgs& a, const int n, Smem* s
         }
         for (; p < p_end; ++p) l_any(p, std::true_type{});
         // input check: one flag per workgroup, read after the last barrier
-        if (!(amax <= LP_ABS_MAX)) *wg_bad = 1;            // benign race: every writer stores 1
-        for (g = p + idx + SHIFT; g < G; ++g) block_barrier();
-        static_assert(NBR == 3 && PSLOTS == 2, "l_step phases are written for a 3-deep register ring");
+        if (colvalid && !(pmin >= P_MIN && pmax <= P_MAX)) *wg_bad = 1;      // benign race: every writer stores non-zero
+        for (int g = p - (lo - DLOAD); g < G; ++g) block_barrier();
+        static_assert(NBR == 3 && PSLOTS == 2 && MSLOTS == 2, "l_step phases are written for these ring depths");
+    };
+    if (role == 1) {
+        if (half_rt == 0) loader(std::integral_constant<int, 0>{});
+        else loader(std::integral_constant<int, 1>{});
         return;
     }
 
-    if (role == 2) {
+    auto storer = [&](auto half_c) {
+        constexpr int half = decltype(half_c)::value;
+        constexpr int k0 = half * KH;
         // ------------------------------ storer ------------------------------
         const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(out, 0, T * U * 4, RSRC_WORD3);
         const int voff_out = colvalid ? uc * 4 : OOB;
         int row_st = row0;
-        // local time p: stores values(p-3), which the compute wave wrote during p-1
+        // local time p: stores values(p-3) and publishes the boundary column of block p-3, both written by the
+        // compute wave during p-1
         auto s_step = [&](const int p, auto guarded) {
             constexpr bool GUARDED = decltype(guarded)::value;
             const int ps = p - 3;
             if (!GUARDED || (ps >= lo && ps < hi)) {
-                const float* src = &sm.vals[ps & (VSLOTS - 1)][lane * VSTRIDE];
-                const int eb = sm.exps[ps & (VSLOTS - 1)][lane];
-                int rows[K];
-                advance(row_st, rows);
-                const int d0 = ps * K;
+                if (has_right && half == 0 && lane < GRAN) {      // (has_right: compile time)
+                    const u64 g = ((u64)block_tag(a.epoch, ps) << 32) | sm.mail_out[ps & (MSLOTS - 1)][lane];
+                    __hip_atomic_store(ring_out + (size_t)ps * GPITCH + lane, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                const float* src = &sm.vals[ps & (VSLOTS - 1)][lane * VSTRIDE + 2 * k0];
+                const int eb = sm.exps[ps & (VSLOTS - 1)][lane] - 1023;
+                int offs[K];
+                advance(row_st, rowb_out, offs);
+                const int d0 = ps * K + k0;
                 const bool full = !GUARDED || full_block(ps);
 #pragma unroll
-                for (int k = 0; k < K; k += 2) {
+                for (int k = 0; k < KH; k += 2) {
                     const f32x4 two = *reinterpret_cast<const f32x4*>(src + 2 * k);   // values k and k+1
 #pragma unroll
                     for (int j = 0; j < 2; ++j) {
@@ -334,35 +450,41 @@ __device__ __forceinline__ void sweep(const LatticeArgs& a, const int n, Smem* s
                         const unsigned mant = __builtin_amdgcn_alignbit(vhi, vlo, 29);
                         const float m = __builtin_bit_cast(float, (mant & 0x007fffffu) | 0x3f800000u);
                         const float l2 = __builtin_amdgcn_logf(m);
-                        const int ex = (int)((vhi >> 20) & 0x7ffu) - 1023 + eb;
+                        const int ex = (int)((vhi >> 20) & 0x7ffu) + eb;
+#ifdef RNNT_PD_NOCONV
+                        const float res = __builtin_bit_cast(float, vhi ^ vlo) + (float)eb;
+#else
                         const float res = __builtin_fmaf((float)ex, LN2, l2 * LN2);
+#endif
                         int voff = voff_out;
                         if (!full) {
                             const bool live = (unsigned)(d0 + k + j - ucol_chk) < (unsigned)Tn;
                             voff = live ? voff_out : OOB;
                         }
-#ifdef RNNT_PD_NOSTORE     // timing probe: no HBM writes (one lane keeps the conversion alive)
+#ifdef RNNT_PD_NOSTORE     // timing probe: no HBM writes (one comparison keeps the conversion alive)
                         if (res == 123.456f)
 #endif
                         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, res), rs_out, voff,
-                                                              rows[k + j] * rowb_out, 0);
+                                                              half ? offs[k + j + KH] : offs[k + j], 0);
                     }
                 }
             }
             block_barrier();
         };
-        const int p_first = lo + 3;
         int g = 0;
-        for (; g < p_first + idx + SHIFT; ++g) block_barrier();
-        int p = p_first;
+        for (; g < 3 + DLOAD; ++g) block_barrier();         // values of block lo exist after interval 4
+        int p = lo + 3;
         const int p_end = hi + 3;
-        int ps0 = max(lo, (wave_c + WAVE - 1 + K - 1) / K) + 3;
-        int ps1 = min(hi, (wave_c + Tn) / K) + 3;          // exclusive
-        if (wave_c + WAVE > Un) ps1 = p_first;             // never "full": no unguarded range
+        const int ps0 = max(lo, (last_col + K - 1) / K) + 3;
+        const int ps1 = min(hi, (wave_c + Tn) / K) + 3;    // exclusive
         for (; p < p_end && p < ps0; ++p) s_step(p, std::true_type{});
         for (; p < ps1; ++p) s_step(p, std::false_type{});
         for (; p < p_end; ++p) s_step(p, std::true_type{});
-        for (g = p + idx + SHIFT; g < G; ++g) block_barrier();
+        // 3+DLOAD + (hi-lo) = G barriers
+    };
+    if (role == 2) {
+        if (half_rt == 0) storer(std::integral_constant<int, 0>{});
+        else storer(std::integral_constant<int, 1>{});
         return;
     }
 
@@ -371,46 +493,39 @@ __device__ __forceinline__ void sweep(const LatticeArgs& a, const int n, Smem* s
     double X = 0.0;
     int E = 0;
     Cell2 bufA[K], bufB[K];
-    // lane 0 reads the left neighbour's boundary column, every other lane reads zeros: the seed term of the
-    // step then needs no predicate
-    const Smem& left = smem[idx > 0 ? idx - 1 : 0];
-    const bool has_right = idx + 1 < nwa;
     auto do_block = [&](const int lb, const Cell2 (&cur)[K], Cell2 (&nxt)[K]) {
         const int d0 = lb * K;
         double seed[K];
         int e_mail = 0;
-        if (idx > 0) {
-            const double* mp = (lane == 0) ? &left.mailx[lb & (MSLOTS - 1)][0] : &left.zeros[0];
+        if constexpr (has_left) {
+            // lane 0 reads the left neighbour's boundary column (staged by the loader one interval ago), every
+            // other lane reads zeros: the seed term of the step then needs no predicate
+            const double* mp = (lane == 0) ? reinterpret_cast<const double*>(&sm.mail_in[lb & (MSLOTS - 1)][0]) : &sm.zeros[0];
 #pragma unroll
             for (int k = 0; k < K; ++k) seed[k] = mp[k];
-            e_mail = left.maile[lb & (MSLOTS - 1)][0];
+            e_mail = (int)sm.mail_in[lb & (MSLOTS - 1)][16];
         }
         const float* next_probs = &sm.probs[(lb + 1) & (PSLOTS - 1)][lane * PSTRIDE];
         float* vdst = &sm.vals[lb & (VSLOTS - 1)][lane * VSTRIDE];
         int* edst = &sm.exps[lb & (VSLOTS - 1)][lane];
-        double* xdst = (lane == WAVE - 1) ? &sm.mailx[lb & (MSLOTS - 1)][0] : &sm.dumpx[lane][0];
-        int* email_dst = (lane == WAVE - 1) ? &sm.maile[lb & (MSLOTS - 1)][0] : &sm.dumpe[lane];
+        double* xdst = (lane == WAVE - 1) ? reinterpret_cast<double*>(&sm.mail_out[lb & (MSLOTS - 1)][0]) : &sm.dumpx[lane][0];
+        int* email_dst = (lane == WAVE - 1) ? reinterpret_cast<int*>(&sm.mail_out[lb & (MSLOTS - 1)][16]) : &sm.dumpe[lane];
         const bool full = full_block(lb);
         const int front = d0 - 1 - wave_c;                 // last lane that has started (may be < 0 or > 63)
         const bool lane_started = (ucol <= d0 - 1) || (ucol == 0);
         const bool started_all = front >= WAVE - 1;
-#define RNNT_PD_CALL(MASKED, SEED, MAIL)                                                                      \
+#define RNNT_PD_CALL(MASKED, SEED, MAIL)                                                                           \
     compute_block<BETA, MASKED, SEED, MAIL>(cur, nxt, seed, e_mail, Y, X, E, d0, ucol_chk, Tn, front, started_all, \
                                             lane_started, next_probs, vdst, xdst, edst, email_dst)
-        if (idx > 0) {
-            if (full) { if (has_right) RNNT_PD_CALL(false, true, true); else RNNT_PD_CALL(false, true, false); }
-            else { if (has_right) RNNT_PD_CALL(true, true, true); else RNNT_PD_CALL(true, true, false); }
-        } else {
-            if (full) { if (has_right) RNNT_PD_CALL(false, false, true); else RNNT_PD_CALL(false, false, false); }
-            else { if (has_right) RNNT_PD_CALL(true, false, true); else RNNT_PD_CALL(true, false, false); }
-        }
+        if (full) RNNT_PD_CALL(false, HAS_LEFT, HAS_RIGHT);
+        else RNNT_PD_CALL(true, HAS_LEFT, HAS_RIGHT);
 #undef RNNT_PD_CALL
         block_barrier();
     };
-    if (lane < K) sm.zeros[lane] = 0.0;                    // before the first barrier this wave takes part in
+    if (lane < K) sm.zeros[lane] = 0.0;                    // before the first barrier
     int g = 0;
-    for (; g < lo + idx + 1 + SHIFT; ++g) block_barrier();
-    {   // first block: written by the loader during the previous interval
+    for (; g < 1 + DLOAD; ++g) block_barrier();            // the loader converts block lo during interval DLOAD
+    {
         const float* src = &sm.probs[lo & (PSLOTS - 1)][lane * PSTRIDE];
 #pragma unroll
         for (int k = 0; k < K; ++k) {
@@ -425,7 +540,7 @@ __device__ __forceinline__ void sweep(const LatticeArgs& a, const int n, Smem* s
         do_block(lb + 1, bufB, bufA);
     }
     if (lb < hi) { do_block(lb, bufA, bufB); ++lb; }
-    for (g = lb + idx + 2 + SHIFT; g < G; ++g) block_barrier();
+    for (g = (lb - lo) + 2 + DLOAD; g < G; ++g) block_barrier();
     if constexpr (!BETA) {
         // the finished last column holds (alpha * pB)(T-1,U-1) in Y: the alpha-side log-likelihood
         // (core_gather.cu:339); once per utterance, so libm's fp64 log2 is affordable
@@ -434,55 +549,93 @@ __device__ __forceinline__ void sweep(const LatticeArgs& a, const int n, Smem* s
 }
 
 template <bool COMPACT>
-__global__ void __launch_bounds__(3 * MAXA * WAVE) k_lattice_pd(const LatticeArgs a) {
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    Smem* smem = reinterpret_cast<Smem*>(smem_raw);
-    __shared__ int wg_bad;
-    // same XCD-aware (utterance, direction) -> workgroup map as k_lattice_ws: the two sweeps of an utterance
-    // read the same plane from opposite ends and share an XCD's L2 (speed only)
-    const unsigned b = blockIdx.x, pairs_total = gridDim.x >> 1;
-    const unsigned grp = b >> 4, in = b & 15;
-    unsigned n, dir;
-    if ((grp << 3) + 8 <= pairs_total) { n = (grp << 3) + (in & 7); dir = in >> 3; }
-    else { const unsigned r = b - (grp << 4); n = (grp << 3) + (r >> 1); dir = r & 1; }   // tail group
-    if (threadIdx.x == 0) wg_bad = 0;
+__global__ void __launch_bounds__(5 * WAVE) k_lattice_pd(const LatticeArgs a, const int nA) {
+    __shared__ Smem sm;
+    __shared__ int wg_bad, s_item;
+    // work items in column-block-major order from an atomic counter: the workgroup that holds item i knows that
+    // every item < i -- in particular its left neighbour, item i - 2N -- is held by a workgroup that has started
+    if (threadIdx.x == 0) { s_item = atomicAdd(a.queue, 1); wg_bad = 0; }
     __syncthreads();
-    if (dir)
-        sweep<true, COMPACT>(a, n, smem, &wg_bad);
-    else
-        sweep<false, COMPACT>(a, n, smem, &wg_bad);
-    // every wave has left its barrier sequence (or never had one): waves arrive here in any order, so the
-    // flag is published by whoever saw it set, and cleared by thread 0 only if nobody did
+    const int sweeps = gridDim.x / nA;                 // 2N
+    Item it;
+    it.cb = s_item / sweeps;
+    const int s = s_item - it.cb * sweeps;
+    it.n = s >> 1;
+    it.dir = s & 1;
+    const UttLens len = utt_lens<COMPACT>(a.xn, a.yn, it.n, a.T, a.U);
+    if (!COMPACT || len.ok) {   // (compact: an utterance with bad lengths has no plane of its own to sweep)
+        const bool hl = it.cb > 0, hr = it.cb + 1 < (len.Un + WAVE - 1) / WAVE;
+#define RNNT_PD_SWEEP(B)                                                                    \
+    do {                                                                                    \
+        if (hl) { if (hr) sweep<B, COMPACT, true, true>(a, it, len, nA, sm, &wg_bad);       \
+                  else sweep<B, COMPACT, true, false>(a, it, len, nA, sm, &wg_bad); }       \
+        else { if (hr) sweep<B, COMPACT, false, true>(a, it, len, nA, sm, &wg_bad);         \
+               else sweep<B, COMPACT, false, false>(a, it, len, nA, sm, &wg_bad); }         \
+    } while (0)
+        if (it.dir) RNNT_PD_SWEEP(true); else RNNT_PD_SWEEP(false);
+#undef RNNT_PD_SWEEP
+    }
     __syncthreads();
-    if (threadIdx.x == 0) a.redo[2 * n + dir] = wg_bad;
+    if (threadIdx.x == 0 && wg_bad) atomicOr(&a.redo[2 * it.n + it.dir], wg_bad);
+}
+
+__global__ void __launch_bounds__(256) k_zero_words(int* p, int n) {
+    for (int i = threadIdx.x; i < n; i += 256) p[i] = 0;
 }
 
 }  // namespace pd
 
-// hipErrorNotSupported when the lattice is too wide for one pass of this kernel.
-hipError_t launch_lattice_pd(hipStream_t stream, const LatticeArgs& a, int N) {
+size_t pd_mail_blocks(int T, int U) { return (size_t)(T + U - 1 + pd::K - 1) / pd::K + 1; }
+
+size_t pd_mail_bytes(int N, int T, int U) {
+    const int nA = (U + WAVE - 1) / WAVE;
+    if (nA < 2) return 0;
+    return (size_t)2 * N * (nA - 1) * pd_mail_blocks(T, U) * pd::GPITCH * sizeof(pd::u64);
+}
+
+// Needs a.redo, a.queue (and a.mail when U > 64); zeroes redo and the queue head itself (one memset node).
+hipError_t launch_lattice_pd(hipStream_t stream, const LatticeArgs& a0, int N) {
     if (N <= 0) return hipSuccess;
-    const int nA = (a.U + WAVE - 1) / WAVE;
-    if (nA > pd::MAXA || !a.redo) return hipErrorNotSupported;
-    const size_t lds = sizeof(pd::Smem) * nA;
-    const dim3 grid(2 * N), block(3 * nA * WAVE);
-    static std::atomic<bool> attr_set[2][64];
-    int dev = -1;
-    if (hipGetDevice(&dev) != hipSuccess) dev = -1;
-    const int ci = a.offs ? 1 : 0;
-    const bool tracked = dev >= 0 && dev < 64;
-    if (!tracked || !attr_set[ci][dev].load(std::memory_order_acquire)) {
-        const void* fn = a.offs ? reinterpret_cast<const void*>(&pd::k_lattice_pd<true>)
-                                : reinterpret_cast<const void*>(&pd::k_lattice_pd<false>);
-        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)(sizeof(pd::Smem) * pd::MAXA));
-        if (e != hipSuccess) return e;
-        if (tracked) attr_set[ci][dev].store(true, std::memory_order_release);
+    const int nA = (a0.U + WAVE - 1) / WAVE;
+    if (!a0.redo || !a0.queue || (nA > 1 && !a0.mail)) return hipErrorNotSupported;
+    if ((long long)2 * N * nA >= (1ll << 31)) return hipErrorNotSupported;
+    // launch epoch: granules of earlier launches (same buffer) never validate.  Random start so that a recycled
+    // allocation of another process does not either.
+    static std::atomic<unsigned> epoch{std::random_device{}()};
+    LatticeArgs a = a0;
+    a.epoch = epoch.fetch_add(1, std::memory_order_relaxed) + 1;
+    a.mail_blocks = (int)pd_mail_blocks(a.T, a.U);
+    // redo (2N ints) and the queue head are contiguous in the workspace (api.hip: carve).  One tiny kernel:
+    // hipMemsetAsync of these few bytes becomes two fill kernels of ~5 us each.
+    pd::k_zero_words<<<1, 256, 0, stream>>>(a.redo, 2 * N + 1);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    const dim3 grid(2 * N * nA), block(5 * WAVE);
+    // One workgroup per CU while there are CUs to spare: the dispatcher otherwise packs several of these small
+    // workgroups onto one CU (five fit by LDS) and their waves share its four SIMDs again.  Claiming more than half
+    // of the CU's LDS is the only placement control there is.
+    static const size_t pad_env = getenv("RNNT_PD_LDS_PAD") ? (size_t)atol(getenv("RNNT_PD_LDS_PAD")) : (size_t)-1;
+    size_t pad = 0;
+    if (pad_env != (size_t)-1) pad = pad_env;
+    else if (grid.x <= 256) pad = 84 * 1024 - sizeof(pd::Smem);
+    if (pad > 32 * 1024) {   // > 64 KiB in total needs the opt-in
+        static std::atomic<bool> attr_set[2][64];
+        int dev = -1;
+        if (hipGetDevice(&dev) != hipSuccess) dev = -1;
+        const int ci = a.offs ? 1 : 0;
+        const bool tracked = dev >= 0 && dev < 64;
+        if (!tracked || !attr_set[ci][dev].load(std::memory_order_acquire)) {
+            const void* fn = a.offs ? reinterpret_cast<const void*>(&pd::k_lattice_pd<true>)
+                                    : reinterpret_cast<const void*>(&pd::k_lattice_pd<false>);
+            e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+            if (e != hipSuccess) return e;
+            if (tracked) attr_set[ci][dev].store(true, std::memory_order_release);
+        }
     }
     if (a.offs)
-        pd::k_lattice_pd<true><<<grid, block, lds, stream>>>(a);
+        pd::k_lattice_pd<true><<<grid, block, pad, stream>>>(a, nA);
     else
-        pd::k_lattice_pd<false><<<grid, block, lds, stream>>>(a);
+        pd::k_lattice_pd<false><<<grid, block, pad, stream>>>(a, nA);
     return hipGetLastError();
 }
 
