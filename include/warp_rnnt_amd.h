@@ -5,15 +5,16 @@
  * `stream` (no allocation, no host synchronisation, no global state), so the
  * library is re-entrant across streams and threads.
  *
- * Part 1 mirrors the reference's own C interface for this path
- * (1ytic/warp-rnnt core.h) so that the reference's bindings can link against
- * this library unchanged.  Part 2 is the native interface
+ * Part 1 mirrors the reference's own C interface (1ytic/warp-rnnt core.h: all
+ * five entry points, padded and compact) so that the reference's bindings can
+ * link against this library unchanged.  Part 2 is the native interface
  * the bundled Python host (warp_rnnt/_C.py) uses: it adds a caller-provided
  * workspace so the lattice kernels can run on the diagonal-major layout.
  */
 #ifndef WARP_RNNT_AMD_H
 #define WARP_RNNT_AMD_H
 
+#include <stdbool.h>
 #include <stddef.h>
 #include <stdint.h>
 
@@ -71,6 +72,32 @@ rnntStatus_t run_warp_rnnt_gather(rnntStream_t stream, unsigned int *counts, flo
                                   float *betas, const float *log_probs, float *grads, float *costs,
                                   const int *xn, const int *yn, int N, int T, int U,
                                   float fastemit_lambda);
+
+/*
+ * The reference's compact (ragged packed) entry points -- core.h:41-60, core_compact.cu:360-500 -- under their
+ * own names and argument lists, so that pytorch_binding/binding.cpp (:170, :197, :241) links against this
+ * library whole.  As there: void return, work is enqueued on the NULL stream, every pointer is a device pointer,
+ * memPref / labelPref are the (N,) EXCLUSIVE prefix sums of xn*(yn+1) and yn (binding.cpp:147-160), counts holds
+ * at least 2N words.  Not as there: a failed launch is not exit(-1) (core.h:7-14) but is remembered per host
+ * thread and returned (and cleared) by rnnt_amd_compact_last_status(); lengths with xn < 1 give cost NaN and
+ * touch nothing; required_grad == 0 computes betas and costs only and never writes alphas / grads (the reference
+ * aliases both to betas then, binding.cpp:192-195).  Gradients honour the alpha/beta consistency guard of the
+ * padded kernels (core_gather.cu:341-354), which the reference's compact kernels lack.
+ * The native compact interface further down (rnnt_amd_loss_compact ...) does the same work on the caller's
+ * stream with status codes and is what the bundled host code uses.
+ */
+void run_gather_for_compact(const float *xs, const int *ys, const unsigned int *xn, const unsigned int *yn,
+                            float *gather_xs, long *loc, const unsigned int *memPref,
+                            const unsigned int *labelPref, unsigned int N, unsigned int T, unsigned int U,
+                            unsigned int V, unsigned int blank);
+void run_warp_rnnt_compact(unsigned int *counts, float *alphas, float *betas, const float *log_probs, float *grads,
+                           float *costs, const unsigned int *xn, const unsigned int *yn,
+                           const unsigned int *memPref, const unsigned int *labelPref, unsigned int N,
+                           unsigned int T, unsigned int U, float fastemit_lambda, bool required_grad);
+void run_scatter_grad_for_compact(const float *grad_cost, const float *gather_grad, const long *loc,
+                                  const int *cum_lens, float *scatter_grad, unsigned int STU, unsigned int N,
+                                  unsigned int V, unsigned int blank);
+rnntStatus_t rnnt_amd_compact_last_status(void);
 
 /* ------------------------------------------------------------------------
  * Part 2 -- native interface (workspace-based, diagonal-major lattice layout)

@@ -36,6 +36,7 @@ def pytest_sessionstart(session):
     try:
         from warp_rnnt_amd import _build
         _build.build()
+        _build.build_binding()
         import oracle
         oracle.build()
     except Exception as e:   # let the individual tests report the problem

@@ -149,3 +149,84 @@ def test_compact_offsets_kernel(N):
     np.testing.assert_array_equal(offs.cpu().numpy(), np.concatenate([[0], np.cumsum(cells)]))
     np.testing.assert_array_equal(loffs.cpu().numpy(), np.concatenate([[0], np.cumsum(yn)]).astype(np.int32))
     assert stats.tolist() == [int(cells.sum()), int(yn.sum()), int(xn.max()), int(yn.max())]
+
+
+def _ref_compact_abi(xs, ys, xn, yn, blank, lam, required_grad=True):
+    """The call sequence of the reference's binding (binding.cpp:139-207, 209-247) on the reference-named entry
+    points of the library (core.h:41-60), raw device pointers through ctypes, NULL stream."""
+    import warp_rnnt_amd
+    L = warp_rnnt_amd.load()
+    N, V = len(xn), xs.shape[1]
+    cells = (xn * (yn + 1)).astype(np.int64)
+    STU = int(cells.sum())
+    mem_pref = np.concatenate([[0], np.cumsum(cells)[:-1]]).astype(np.int32)       # exclusive, as binding.cpp:147-160
+    lab_pref = np.concatenate([[0], np.cumsum(yn)[:-1]]).astype(np.int32)
+    txs, tys, txn, tyn = T(xs), T(ys), T(xn), T(yn)
+    tmem, tlab = T(mem_pref), T(lab_pref)
+    gather_xs = torch.empty((STU, 2), device=DEV)
+    loc = torch.zeros((STU,), dtype=torch.int64, device=DEV)
+    torch.cuda.synchronize()          # the entry points use the NULL stream, like the reference
+    L.run_gather_for_compact(txs.data_ptr(), tys.data_ptr(), txn.data_ptr(), tyn.data_ptr(), gather_xs.data_ptr(),
+                             loc.data_ptr(), tmem.data_ptr(), tlab.data_ptr(), N, int(xn.max()), int(yn.max()) + 1, V,
+                             blank)
+    costs = torch.empty((N,), device=DEV)
+    counts = torch.zeros((int(ys.size) * 2 + 2 * N,), dtype=torch.int32, device=DEV)
+    betas = torch.empty((STU,), device=DEV)
+    alphas = torch.empty_like(betas) if required_grad else betas
+    grads = torch.empty_like(gather_xs) if required_grad else betas
+    L.run_warp_rnnt_compact(counts.data_ptr(), alphas.data_ptr(), betas.data_ptr(), gather_xs.data_ptr(),
+                            grads.data_ptr(), costs.data_ptr(), txn.data_ptr(), tyn.data_ptr(), tmem.data_ptr(),
+                            tlab.data_ptr(), N, int(xn.max()), int(yn.max()) + 1, lam, required_grad)
+    torch.cuda.synchronize()
+    assert L.rnnt_amd_compact_last_status() == 0
+    return costs, grads, loc, gather_xs
+
+
+def test_reference_named_compact_entry_points():
+    """run_gather_for_compact / run_warp_rnnt_compact / run_scatter_grad_for_compact (core.h:41-60) on the
+    reference's compact golden vector (test.py:259-336) and on a seeded ragged batch against the oracle."""
+    import warp_rnnt_amd
+    L = warp_rnnt_amd.load()
+    case = [c for c in reference_doc()["cases"] if c["name"] == "forward_batch_compact"][0]
+    lp = np_log_softmax32(np.array(case["logits"], dtype=np.float32))
+    labels = np.array(case["labels"], dtype=np.int32)
+    xn = np.array(case["xn"], dtype=np.int32)
+    yn = np.array(case["yn"], dtype=np.int32)
+    xs, ys = pack(lp, labels, xn, yn)
+    costs, grads, loc, _ = _ref_compact_abi(xs, ys, xn, yn, 0, 0.0)
+    np.testing.assert_allclose(costs.cpu().numpy(), np.array(case["costs"]), atol=1.5e-6, rtol=0)
+    V = lp.shape[-1]
+    STU = xs.shape[0]
+    cumlen = torch.cumsum(T(xn) * (T(yn) + 1), dim=0, dtype=torch.int32)
+    dense = torch.zeros((STU, V), device=DEV)              # binding.cpp:237: zeros, then the scatter
+    ones = torch.ones((len(xn),), device=DEV)
+    torch.cuda.synchronize()
+    L.run_scatter_grad_for_compact(ones.data_ptr(), grads.data_ptr(), loc.data_ptr(), cumlen.data_ptr(),
+                                   dense.data_ptr(), STU, len(xn), V, 0)
+    torch.cuda.synchronize()
+    assert L.rnnt_amd_compact_last_status() == 0
+    np.testing.assert_allclose(dense.cpu().numpy(), np.array(case["grads_rows"]), atol=1.5e-6, rtol=0)
+
+    # seeded ragged batch, two column blocks, FastEmit, blank != 0; and the costs-only mode
+    N, Tm, Um, V, lam, blank = 3, 70, 90, 5, 0.02, 2
+    logits, labels, xn, yn = make_case(77 + Tm, N, Tm, Um, V, ragged=True, blank=blank)
+    lp = np_log_softmax32(logits)
+    ref = oracle.rnnt_loss_f32(lp, labels, xn, yn, blank=blank, fastemit_lambda=lam, scan_mode=1)
+    xs, ys = pack(lp, labels, xn, yn)
+    costs, grads, loc, gx = _ref_compact_abi(xs, ys, xn, yn, blank, lam)
+    np.testing.assert_allclose(costs.cpu().numpy(), ref["costs"], rtol=1e-5)
+    want_pairs = np.concatenate([oracle.gather_f32(lp[n:n + 1, :xn[n], :yn[n] + 1], labels[n:n + 1, :yn[n]], blank)[0]
+                                 .reshape(-1, 2) for n in range(N)])
+    got_pairs = gx.cpu().numpy()
+    lastcol = np.concatenate([np.tile(np.arange(yn[n] + 1) == yn[n], xn[n]) for n in range(N)])
+    np.testing.assert_array_equal(got_pairs[:, 0], want_pairs[:, 0])
+    np.testing.assert_array_equal(got_pairs[~lastcol, 1], want_pairs[~lastcol, 1])
+    g2 = np.concatenate([oracle.gather_f32(ref["grads"][n:n + 1, :xn[n], :yn[n] + 1], labels[n:n + 1, :yn[n]], blank)[0]
+                         .reshape(-1, 2) for n in range(N)])
+    g2[lastcol, 1] = 0
+    np.testing.assert_allclose(grads.cpu().numpy(), g2, atol=1e-4)
+    c2, _, _, _ = _ref_compact_abi(xs, ys, xn, yn, blank, lam, required_grad=False)
+    np.testing.assert_allclose(c2.cpu().numpy(), ref["costs"], rtol=1e-5)
+    # bad arguments are reported, not fatal
+    L.run_scatter_grad_for_compact(None, None, None, None, None, 1, 1, 3, 7)
+    assert L.rnnt_amd_compact_last_status() == 5 and L.rnnt_amd_compact_last_status() == 0

@@ -241,3 +241,40 @@ def test_joint_benchmark_cli_runs(extra):
                               "--hidden", "16"] + extra, env=env, capture_output=True, text=True, timeout=300)
         assert out.returncode == 0, out.stderr[-2000:]
         assert "| 20 | 5 | 11 | 3 |" in out.stdout
+
+
+def test_both_host_bindings_give_the_same_bits():
+    """The compiled binding (warp_rnnt._C_native) and the ctypes fallback drive the same library: the golden
+    vectors and a seeded gather=True case through both, bit for bit (the fallback in a subprocess, selected with
+    WARP_RNNT_AMD_NO_NATIVE_BINDING)."""
+    import os
+    import subprocess
+    import sys
+    import warp_rnnt._C as core
+    assert core._native is not None
+    code = r"""
+import sys, numpy as np, torch
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import warp_rnnt, warp_rnnt._C as core
+from helpers import make_case, np_log_softmax32
+assert (core._native is None) == bool(int(sys.argv[1]))
+logits, labels, xn, yn = make_case(9, 5, 37, 70, 11, ragged=True)
+d = torch.device("cuda:0")
+lp = torch.tensor(np_log_softmax32(logits), device=d, requires_grad=True)
+c = warp_rnnt.rnnt_loss(lp, torch.tensor(labels, device=d), torch.tensor(xn, device=d), torch.tensor(yn, device=d),
+                        gather=bool(int(sys.argv[2])), fastemit_lambda=0.01)
+(c * torch.arange(1, 6, device=d)).sum().backward()
+sys.stdout.buffer.write(c.detach().cpu().numpy().tobytes() + lp.grad.cpu().numpy().tobytes())
+""" % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)))
+    for gather in ("0", "1"):
+        outs = []
+        for no_native in ("0", "1"):
+            env = dict(os.environ)
+            env.pop("WARP_RNNT_AMD_NO_NATIVE_BINDING", None)
+            if no_native == "1":
+                env["WARP_RNNT_AMD_NO_NATIVE_BINDING"] = "1"
+            r = subprocess.run([sys.executable, "-c", code, no_native, gather], env=env, stdout=subprocess.PIPE,
+                               stderr=subprocess.PIPE, timeout=300)
+            assert r.returncode == 0, r.stderr.decode()[-2000:]
+            outs.append(r.stdout)
+        assert len(outs[0]) > 1000 and outs[0] == outs[1]

@@ -24,7 +24,10 @@ def test_header_symbols_exported():
     from warp_rnnt_amd import _build, _lib
     _build.build()          # hipcc cross-compiles for gfx950 without a GPU; no-op when up to date
     hdr = open(os.path.join(ROOT, "include", "warp_rnnt_amd.h")).read()
-    declared = set(re.findall(r"\b(run_warp_rnnt(?:_gather)?|rnnt_amd_[a-z_]+)\s*\(", hdr))
+    declared = set(re.findall(r"\b(run_[a-z_]+|rnnt_amd_[a-z_]+)\s*\(", hdr))
+    # the reference's whole C interface (core.h:29-60) is there under its own names
+    assert {"run_warp_rnnt", "run_warp_rnnt_gather", "run_gather_for_compact", "run_warp_rnnt_compact",
+            "run_scatter_grad_for_compact"} <= declared
     assert {"run_warp_rnnt", "run_warp_rnnt_gather", "rnnt_amd_loss", "rnnt_amd_expand_grads",
             "rnnt_amd_log_softmax", "rnnt_amd_gather", "rnnt_amd_workspace_size"} <= declared
     assert declared == set(_lib.SYMBOLS), (declared ^ set(_lib.SYMBOLS))
@@ -222,3 +225,27 @@ def test_bench_self_launches_ranks_gloo_dry():
                          env=dict(env, WORLD_SIZE="1", RANK="0"), stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
                          timeout=120)
     assert bad.returncode != 0 and b"launcher started 1 rank" in bad.stdout
+
+
+def test_compiled_binding_is_built_and_checks_arguments_like_the_reference():
+    """warp_rnnt._C_native (csrc/binding.cpp): the reference's check order and texts (binding.cpp:32-51, test.py:15-32)
+    come from TORCH_CHECK there; whatever can be observed without a GPU is observed here."""
+    import warp_rnnt._C as core
+    assert core._native is not None, "warp_rnnt/_C_native.so has not been built (_build.build_binding)"
+    nat = core._native
+    for fn in ("rnnt_loss", "rnnt_loss_gather", "rnnt_loss_gather_backward", "log_softmax", "library_version"):
+        assert hasattr(nat, fn)
+    xs = torch.tensor([], dtype=torch.float32)
+    e = torch.tensor([], dtype=torch.int)
+    nc = torch.tensor(np.zeros((4, 3, 2, 1)), dtype=torch.float32).transpose(0, 1)
+    with pytest.raises(RuntimeError, match="xs must be contiguous"):
+        nat.rnnt_loss(nc, e, e, e)
+    with pytest.raises(RuntimeError, match="xs must be located in the CUDA"):
+        nat.rnnt_loss(xs, e, e, e)
+    with pytest.raises(RuntimeError, match="ys must be a Int tensor"):
+        nat.rnnt_loss(xs, torch.tensor([], dtype=torch.long), e, e)
+    with pytest.raises(RuntimeError, match="xs must be a Float tensor"):
+        nat.rnnt_loss(xs.half(), e, e, e)
+    # keyword names of the reference's module (binding.cpp:250-254; used as kwargs at __init__.py:13-18)
+    with pytest.raises(RuntimeError, match="located in the CUDA"):
+        nat.rnnt_loss(xs=xs, ys=e, xn=e, yn=e, blank=0, fastemit_lambda=0.0)

@@ -4,9 +4,19 @@ error texts as the reference's pybind module ``warp_rnnt._C``
 libwarp_rnnt_amd.so through ctypes.  There is no CPU path: tensors must live on a GPU
 ("CUDA" device type under PyTorch-ROCm) and the HIP library must be built.
 """
+import os
+import warnings
+
 import torch
 
 from warp_rnnt_amd import ops as _ops
+
+try:                     # the compiled binding (warp_rnnt_amd/csrc/binding.cpp, built by _build.build_binding)
+    from . import _C_native as _native
+except ImportError:      # not built: the ctypes path below does the same work, a few tens of microseconds slower
+    _native = None
+if os.environ.get("WARP_RNNT_AMD_NO_NATIVE_BINDING"):
+    _native = None
 
 
 def _check_contiguous(x, name):
@@ -51,8 +61,25 @@ def check_inputs(xs, ys, xn, yn):
             raise RuntimeError(f"{name} must be on the same device as xs")
 
 
+def _native_call(fn, xs, ys, xn, yn, blank, fastemit_lambda):
+    """One call into the compiled binding; WARP_RNNT_AMD_CHECK_MISMATCH handled as in ops.loss."""
+    policy = os.environ.get("WARP_RNNT_AMD_CHECK_MISMATCH", "").lower()
+    costs, grads, mismatch = fn(xs, ys, xn, yn, blank, fastemit_lambda, bool(policy))
+    if policy:
+        bad = mismatch.nonzero().flatten().tolist()          # host synchronisation (opt-in)
+        if bad:
+            msg = (f"rnnt_loss: forward/backward mismatch or invalid lengths for utterance(s) {bad}: "
+                   "their gradients are zero (core_gather.cu:341-354)")
+            if policy == "raise":
+                raise RuntimeError(msg)
+            warnings.warn(msg, RuntimeWarning, stacklevel=3)
+    return costs, grads
+
+
 def rnnt_loss(xs, ys, xn, yn, blank=0, fastemit_lambda=0.0):
     """(costs (N,), grads like xs).  blank == -1 selects the gathered (N,T,U,2) layout."""
+    if _native is not None:
+        return _native_call(_native.rnnt_loss, xs, ys, xn, yn, blank, fastemit_lambda)
     check_inputs(xs, ys, xn, yn)
     if blank == -1:
         if xs.size(3) != 2:
@@ -65,6 +92,8 @@ def rnnt_loss(xs, ys, xn, yn, blank=0, fastemit_lambda=0.0):
 def rnnt_loss_gather(xs, ys, xn, yn, blank=0, fastemit_lambda=0.0):
     """Native form of the wrapper's ``gather=True`` branch: dense log-probs in, costs and the
     (opaque, diagonal-major) gathered gradients out; feed those to :func:`rnnt_loss_gather_backward`."""
+    if _native is not None:
+        return _native_call(_native.rnnt_loss_gather, xs, ys, xn, yn, blank, fastemit_lambda)
     check_inputs(xs, ys, xn, yn)
     return _ops.loss(xs, ys, xn, yn, _ops.IN_LOG_PROBS_DENSE, _ops.GRADS_GATHERED_DIAGONAL,
                      blank, fastemit_lambda)
@@ -72,6 +101,8 @@ def rnnt_loss_gather(xs, ys, xn, yn, blank=0, fastemit_lambda=0.0):
 
 def rnnt_loss_gather_backward(grad_costs, grads_diagonal, ys, xn, yn, V, blank=0):
     """d loss / d log_probs (N,T,U,V) = scatter-add of the gathered grads times grad_costs[n]."""
+    if _native is not None:
+        return _native.rnnt_loss_gather_backward(grad_costs, grads_diagonal, ys, xn, yn, V, blank)
     return _ops.expand_grads(grads_diagonal, ys, xn, yn, grad_costs, V, blank, overwrite=False)
 
 

@@ -103,6 +103,41 @@ def build(force=False, verbose=False, extra_flags=(), variant=None):
     return lib
 
 
+BINDING_SRC = os.path.join(CSRC, "binding.cpp")
+BINDING = os.path.normpath(os.path.join(HERE, "..", "warp_rnnt", "_C_native.so"))
+
+
+def build_binding(force=False, verbose=False):
+    """Compile warp_rnnt/_C_native.so: the pybind/ATen host binding over libwarp_rnnt_amd.so (host code only, g++).
+    Returns the path, or None when the toolchain pieces are missing (the ctypes module then serves)."""
+    import sysconfig
+    import torch
+    from torch.utils import cpp_extension as ce
+    lib = build()                                   # the kernels' library it links against
+    hdr = os.path.normpath(os.path.join(CSRC, "..", "..", "include", "warp_rnnt_amd.h"))
+    gxx = shutil.which(os.environ.get("CXX", "g++"))
+    if gxx is None:
+        return None
+    tdir = os.path.dirname(torch.__file__)
+    flags = ["-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-function", "-D__HIP_PLATFORM_AMD__=1",
+             "-DUSE_ROCM=1", "-DTORCH_EXTENSION_NAME=_C_native", "-DTORCH_API_INCLUDE_EXTENSION_H",
+             "-D_GLIBCXX_USE_CXX11_ABI=%d" % int(torch._C._GLIBCXX_USE_CXX11_ABI)]
+    incs = ["-I" + p for p in ce.include_paths(device_type="cuda")] + ["-I" + sysconfig.get_paths()["include"]]
+    libs = ["-L" + os.path.join(tdir, "lib"), "-L" + HERE, "-lwarp_rnnt_amd", "-lc10", "-lc10_hip", "-ltorch_cpu",
+            "-ltorch_hip", "-ltorch", "-ltorch_python",
+            "-Wl,-rpath,$ORIGIN/../warp_rnnt_amd", "-Wl,-rpath," + os.path.join(tdir, "lib")]
+    fp = _fingerprint([BINDING_SRC, hdr], flags + incs + [torch.__version__])
+    if not force and os.path.exists(BINDING) and _read(BINDING + ".fingerprint") == fp:
+        return BINDING
+    cmd = [gxx] + flags + incs + [BINDING_SRC, "-o", BINDING] + libs
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    with open(BINDING + ".fingerprint", "w") as f:
+        f.write(fp)
+    return BINDING
+
+
 def ensure_built():
     """Build the library if it is missing, safely when several ranks of one node start together
     (exclusive file lock; the others find it built).  This is what bench.py and smoke() call; the

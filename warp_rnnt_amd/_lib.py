@@ -27,6 +27,10 @@ _vp, _i, _f, _sz, _i64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c
 SYMBOLS = {
     "run_warp_rnnt": (_i, [_vp] * 10 + [_i] * 5 + [_f]),
     "run_warp_rnnt_gather": (_i, [_vp] * 9 + [_i] * 3 + [_f]),
+    "run_gather_for_compact": (None, [_vp] * 8 + [ctypes.c_uint] * 5),
+    "run_warp_rnnt_compact": (None, [_vp] * 10 + [ctypes.c_uint] * 3 + [_f, ctypes.c_bool]),
+    "run_scatter_grad_for_compact": (None, [_vp] * 5 + [ctypes.c_uint] * 4),
+    "rnnt_amd_compact_last_status": (_i, []),
     "rnnt_amd_workspace_size": (_sz, [_i, _i, _i]),
     "rnnt_amd_workspace_mismatch_offset": (_sz, [_i, _i, _i]),
     "rnnt_amd_loss": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f]),

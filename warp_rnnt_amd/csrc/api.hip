@@ -223,6 +223,67 @@ rnntStatus_t rnnt_amd_compact_scatter_grads(rnntStream_t stream, const float* gr
     return RNNT_STATUS_SUCCESS;
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// The reference's own compact entry points (core.h:41-60), same names and argument lists, so that its
+// binding.cpp links against this library whole.  Kept conventions: void return, the NULL stream (its binding
+// relies on stream 0: it launches nothing on a stream of its own, binding.cpp:170,197,241).  Changed: a failed
+// launch does not exit(-1) the process (core.h:7-14) but is remembered per thread -- rnnt_amd_compact_last_status().
+// ---------------------------------------------------------------------------------------------------------
+static thread_local rnntStatus_t g_compact_status = RNNT_STATUS_SUCCESS;
+
+rnntStatus_t rnnt_amd_compact_last_status(void) {
+    const rnntStatus_t s = g_compact_status;
+    g_compact_status = RNNT_STATUS_SUCCESS;
+    return s;
+}
+
+void run_gather_for_compact(const float* xs, const int* ys, const unsigned int* xn, const unsigned int* yn,
+                            float* gather_xs, long* loc, const unsigned int* memPref,
+                            const unsigned int* labelPref, unsigned int N, unsigned int T, unsigned int U,
+                            unsigned int V, unsigned int blank) {
+    static_assert(sizeof(long) == sizeof(int64_t), "loc is the reference's `long` (at::kLong)");
+    if (V < 1 || blank >= V) { g_compact_status = RNNT_STATUS_INVALID_ARGUMENT; return; }
+    if (launch_gather_compact_rowmajor(nullptr, xs, ys, xn, yn, gather_xs, reinterpret_cast<int64_t*>(loc), memPref,
+                                       labelPref, N, T, U, V, blank) != hipSuccess)
+        g_compact_status = RNNT_STATUS_PROLOGUE_FAILED;
+}
+
+void run_warp_rnnt_compact(unsigned int* counts, float* alphas, float* betas, const float* log_probs, float* grads,
+                           float* costs, const unsigned int* xn, const unsigned int* yn,
+                           const unsigned int* memPref, const unsigned int* labelPref, unsigned int N,
+                           unsigned int T, unsigned int U, float fastemit_lambda, bool required_grad) {
+    (void)labelPref;
+    if (N == 0) return;
+    if (!dims_ok((int)N, T > 0 ? (int)T : 1, U > 0 ? (int)U : 1)) { g_compact_status = RNNT_STATUS_INVALID_ARGUMENT; return; }
+    const int* ixn = reinterpret_cast<const int*>(xn);
+    const int* iyn = reinterpret_cast<const int*>(yn);
+    // counts (2*sum(yn) + 2N words, binding.cpp:187): the first N hold the alpha-side log-likelihoods
+    float* ll = reinterpret_cast<float*>(counts);
+    LatticeArgs la{log_probs, nullptr, ixn, iyn, alphas, betas, ll, (int)T, (int)U, 2, 0};
+    la.offs32 = memPref;
+    la.beta_only = required_grad ? 0 : 1;
+    if (launch_lattice(nullptr, la, (int)N, LOAD_ROWMAJOR2) != hipSuccess) { g_compact_status = RNNT_STATUS_WARP_FAILED; return; }
+    if (!required_grad) {   // the reference's "beta only" inference mode: costs from beta[0,0], nothing else is touched
+        if (launch_costs_from_betas(nullptr, betas, memPref, ixn, iyn, costs, (int)N) != hipSuccess)
+            g_compact_status = RNNT_STATUS_COSTS_FAILED;
+        return;
+    }
+    GradArgs ga{log_probs, nullptr, ixn, iyn, alphas, betas, ll, grads, costs, nullptr, (int)T, (int)U, 2, 0,
+                fastemit_lambda};
+    ga.offs32 = memPref;
+    if (launch_grads(nullptr, ga, (int)N, LOAD_ROWMAJOR2, WRITE_ROWMAJOR2) != hipSuccess)
+        g_compact_status = RNNT_STATUS_GRADS_BLANK_FAILED;
+}
+
+void run_scatter_grad_for_compact(const float* grad_cost, const float* gather_grad, const long* loc,
+                                  const int* cum_lens, float* scatter_grad, unsigned int STU, unsigned int N,
+                                  unsigned int V, unsigned int blank) {
+    if (V < 1 || blank >= V) { g_compact_status = RNNT_STATUS_INVALID_ARGUMENT; return; }
+    if (launch_scatter_compact(nullptr, grad_cost, gather_grad, reinterpret_cast<const int64_t*>(loc), cum_lens,
+                               scatter_grad, (int64_t)STU, (int)N, (int)V, (int)blank) != hipSuccess)
+        g_compact_status = RNNT_STATUS_EXPAND_FAILED;
+}
+
 rnntStatus_t rnnt_amd_expand_grads(rnntStream_t stream, const float* grads_diagonal, const int* labels,
                                    const int* xn, const int* yn, const float* grad_costs,
                                    float* dense_grads, int N, int T, int U, int V, int blank,

@@ -31,7 +31,7 @@ __global__ void __launch_bounds__(256) k_grads(const GradArgs a) {
     }
     const int Tn = len.Tn, Un = len.Un;
     const int T = COMPACT ? Tn : a.T, U = COMPACT ? Un : a.U;     // compact: per-utterance planes
-    const size_t nb = COMPACT ? (size_t)a.offs[n] : (size_t)n * T * U;
+    const size_t nb = COMPACT ? compact_base(a, n) : (size_t)n * T * U;
     const float* __restrict__ al = a.alphas + nb;
     const float* __restrict__ be = a.betas + nb;
 
@@ -112,7 +112,11 @@ static hipError_t launch_grads_w(hipStream_t stream, const GradArgs& a, dim3 gri
 hipError_t launch_grads(hipStream_t stream, const GradArgs& a, int N, int loader, int writer) {
     if (N <= 0) return hipSuccess;
     const dim3 grid(((unsigned)(a.T * a.U) + 255u) / 256u, (unsigned)N);
-    if (a.offs) {   // compact layout (a.T, a.U = maxima): diagonal-major pairs in, packed pairs out
+    if (is_compact(a)) {   // compact layout (a.T, a.U = maxima): packed pairs out
+        if (loader == LOAD_ROWMAJOR2) {   // row-major packed pairs in (core.h shims)
+            k_grads<LOAD_ROWMAJOR2, WRITE_ROWMAJOR2, true><<<grid, 256, 0, stream>>>(a);
+            return hipGetLastError();
+        }
         if (writer == WRITE_ROWMAJOR2)
             k_grads<LOAD_SKEWED, WRITE_ROWMAJOR2, true><<<grid, 256, 0, stream>>>(a);
         else
@@ -124,6 +128,24 @@ hipError_t launch_grads(hipStream_t stream, const GradArgs& a, int N, int loader
         case LOAD_ROWMAJOR2: return launch_grads_w<LOAD_ROWMAJOR2>(stream, a, grid, writer);
         default:             return launch_grads_w<LOAD_DENSE>(stream, a, grid, writer);
     }
+}
+
+// cost[n] = -beta[0,0] for a compact batch whose alpha sweep was skipped (run_warp_rnnt_compact with
+// required_grad = false; core_compact.cu:349-357).  Cell (0,0) is the first cell of the diagonal-major plane too.
+__global__ void k_costs_from_betas(const float* __restrict__ betas, const unsigned* __restrict__ mem_pref,
+                                   const int* __restrict__ xn, const int* __restrict__ yn, float* __restrict__ costs,
+                                   int N) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    const bool ok = xn[n] >= 1 && yn[n] >= 0;
+    costs[n] = ok ? -betas[mem_pref[n]] : __builtin_nanf("");
+}
+
+hipError_t launch_costs_from_betas(hipStream_t stream, const float* betas, const unsigned* mem_pref, const int* xn,
+                                   const int* yn, float* costs, int N) {
+    if (N <= 0) return hipSuccess;
+    k_costs_from_betas<<<(N + 255) / 256, 256, 0, stream>>>(betas, mem_pref, xn, yn, costs, N);
+    return hipGetLastError();
 }
 
 }  // namespace rnnt

@@ -23,7 +23,12 @@ struct LatticeArgs {
     unsigned long long* mail;  // its hand-over rings between column blocks (pd_mail_bytes), needed when U > 64
     int mail_blocks;      // filled in by launch_lattice_pd
     unsigned epoch;       // filled in by launch_lattice_pd
+    const unsigned* offs32;  // compact layout with the reference's 32-bit offsets (run_warp_rnnt_compact); used when
+                             // offs is null
+    int beta_only;        // compact shim, required_grad = false: the alpha sweep is skipped (its buffer aliases betas)
 };
+__host__ __device__ inline bool is_compact(const LatticeArgs& a) { return a.offs || a.offs32; }
+__device__ inline size_t compact_base(const LatticeArgs& a, int n) { return a.offs ? (size_t)a.offs[n] : (size_t)a.offs32[n]; }
 
 struct GradArgs {
     const float* lp;      // as LatticeArgs
@@ -39,7 +44,10 @@ struct GradArgs {
     int T, U, V, blank;
     float fastemit_lambda;
     const int64_t* offs;  // as LatticeArgs
+    const unsigned* offs32;
 };
+__host__ __device__ inline bool is_compact(const GradArgs& a) { return a.offs || a.offs32; }
+__device__ inline size_t compact_base(const GradArgs& a, int n) { return a.offs ? (size_t)a.offs[n] : (size_t)a.offs32[n]; }
 
 hipError_t launch_lattice(hipStream_t stream, const LatticeArgs& a, int N, int loader);
 // wave-specialised log-domain variant (diagonal-major loader only); hipErrorNotSupported when U > 512.
@@ -59,6 +67,13 @@ hipError_t launch_gather(hipStream_t stream, const float* log_probs, const int* 
                          int N, int T, int U, int V, int blank, bool skewed);
 hipError_t launch_reskew(hipStream_t stream, const float* lp2_rowmajor, float* ws2, int N, int T, int U);
 // compact (ragged packed) layout, core_compact.cu:403-436,456-484
+// reference-layout compact helpers (core.h:41-60 shims): row-major packed pairs + loc; costs from betas alone
+hipError_t launch_gather_compact_rowmajor(hipStream_t stream, const float* xs, const int* ys, const unsigned* xn,
+                                          const unsigned* yn, float* gather_xs, int64_t* loc, const unsigned* mem_pref,
+                                          const unsigned* label_pref, unsigned N, unsigned T, unsigned U, unsigned V,
+                                          unsigned blank);
+hipError_t launch_costs_from_betas(hipStream_t stream, const float* betas, const unsigned* mem_pref, const int* xn,
+                                   const int* yn, float* costs, int N);
 hipError_t launch_compact_offsets(hipStream_t stream, const int* xn, const int* yn, int N, int64_t* cell_offs,
                                   int* label_offs, int64_t* stats);
 hipError_t launch_gather_compact(hipStream_t stream, const float* xs, const int* ys, const int* xn,

@@ -223,7 +223,7 @@ __device__ __forceinline__ void sweep(const LatticeArgs& a, const int n, float (
     const int lane = threadIdx.x & (WAVE - 1);
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform
     const int nw = blockDim.x >> 6;
-    const size_t nbase = COMPACT ? (size_t)a.offs[n] : (size_t)n * T * U;
+    const size_t nbase = COMPACT ? compact_base(a, n) : (size_t)n * T * U;
     float* out = (BETA ? a.betas : a.alphas) + nbase;
     if (Un == 1) {   // no labels: prefix / suffix sums by one wave (see common.h); uniform, before any barrier
         if (w == 0) {
@@ -435,6 +435,7 @@ __global__ void __launch_bounds__(MAXW * WAVE) k_lattice(const LatticeArgs a) {
     unsigned n, dir;
     if ((grp << 3) + 8 <= pairs_total) { n = (grp << 3) + (in & 7); dir = in >> 3; }
     else { const unsigned r = b - (grp << 4); n = (grp << 3) + (r >> 1); dir = r & 1; }   // tail group
+    if (a.beta_only && !dir) return;
     if (dir)
         sweep<LOADER, true, COMPACT>(a, n, mail, trash);
     else
@@ -456,9 +457,9 @@ hipError_t launch_lattice(hipStream_t stream, const LatticeArgs& a, int N, int l
         // behind it must be able to redo a sweep.  RNNT_LATTICE=logdomain|pd overrides the choice (A/B runs).
         static const char* force = getenv("RNNT_LATTICE");
         const int nA = (a.U + WAVE - 1) / WAVE;
-        bool use_pd = a.redo && a.queue && !a.offs && nA <= 8 && (long long)2 * N * nA <= 320 && a.T + a.U >= 1024;
+        bool use_pd = a.redo && a.queue && !is_compact(a) && nA <= 8 && (long long)2 * N * nA <= 320 && a.T + a.U >= 1024;
         if (force && force[0] == 'l') use_pd = false;
-        if (force && force[0] == 'p') use_pd = a.redo && a.queue && !a.offs && nA <= 8;
+        if (force && force[0] == 'p') use_pd = a.redo && a.queue && !is_compact(a) && nA <= 8;
         if (use_pd) {
             const hipError_t e = launch_lattice_pd(stream, a, N);
             if (e == hipSuccess) return launch_lattice_ws(stream, a, N);
@@ -475,8 +476,9 @@ hipError_t launch_lattice(hipStream_t stream, const LatticeArgs& a, int N, int l
     int waves = (a.U + WAVE - 1) / WAVE;
     waves = waves < 1 ? 1 : (waves > MAXW ? MAXW : waves);
     const dim3 grid(2 * N), block(waves * WAVE);
-    if (a.offs) {   // compact layout: only the diagonal-major loader is used
-        k_lattice<LOAD_SKEWED, true><<<grid, block, 0, stream>>>(a);
+    if (is_compact(a)) {   // compact layout: diagonal-major pairs (native path) or row-major pairs (core.h shims)
+        if (loader == LOAD_ROWMAJOR2) k_lattice<LOAD_ROWMAJOR2, true><<<grid, block, 0, stream>>>(a);
+        else k_lattice<LOAD_SKEWED, true><<<grid, block, 0, stream>>>(a);
         return hipGetLastError();
     }
     switch (loader) {

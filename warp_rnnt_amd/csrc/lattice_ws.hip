@@ -165,7 +165,7 @@ __device__ __forceinline__ void sweep(const LatticeArgs& a, const int n, Smem* s
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (Un == 1) {   // no labels: prefix / suffix sums by one wave (uniform over the workgroup, no barrier yet)
         if (w == 0) {
-            const size_t nb1 = COMPACT ? (size_t)a.offs[n] : (size_t)n * T * U;
+            const size_t nb1 = COMPACT ? compact_base(a, n) : (size_t)n * T * U;
             const float2* lp2 = reinterpret_cast<const float2*>(a.lp) + nb1;
             const float total = single_column_scan<BETA>(Tn, (BETA ? a.betas : a.alphas) + nb1, U, lane,
                                                          [&](int t) { return lp2[(size_t)t * U].x; });
@@ -176,7 +176,7 @@ __device__ __forceinline__ void sweep(const LatticeArgs& a, const int n, Smem* s
     const int nA = blockDim.x >> 7;                   // compute waves = I/O waves
     const bool is_io = w >= nA;
     const int idx = is_io ? w - nA : w;               // column block
-    const size_t nbase = COMPACT ? (size_t)a.offs[n] : (size_t)n * T * U;
+    const size_t nbase = COMPACT ? compact_base(a, n) : (size_t)n * T * U;
     float* out = (BETA ? a.betas : a.alphas) + nbase;
     const int ndiag = Tn + Un - 1;
     const float NEG_INF = -__builtin_inff();

@@ -740,6 +740,38 @@ hipError_t launch_gather_compact(hipStream_t stream, const float* xs, const int*
     return hipGetLastError();
 }
 
+// The reference's own compact gather (core_compact.cu:403-450, run_gather_for_compact): ROW-MAJOR packed pairs
+// (STU,2) and loc (STU,), 32-bit exclusive offsets.  One thread per cell; serves the core.h shims of api.hip.
+__global__ void __launch_bounds__(256)
+k_gather_compact_rowmajor(const float* __restrict__ xs, const int* __restrict__ ys, const unsigned* __restrict__ xn,
+                          const unsigned* __restrict__ yn, float2* __restrict__ out2, int64_t* __restrict__ loc,
+                          const unsigned* __restrict__ mem_pref, const unsigned* __restrict__ label_pref, unsigned V,
+                          unsigned blank) {
+    const unsigned n = blockIdx.y;
+    const unsigned Tn = xn[n], Un = yn[n] + 1;
+    if ((int)Tn < 1 || (int)Un < 1) return;
+    const unsigned c = blockIdx.x * 256u + threadIdx.x;
+    if (c >= Tn * Un) return;
+    const unsigned u = c % Un;
+    const size_t index = (size_t)mem_pref[n] + c;
+    const int l = (u == Un - 1) ? (int)blank : safe_label(ys[label_pref[n] + u], (int)V, (int)blank);
+    const float* p = xs + index * (size_t)V;
+    out2[index] = make_float2(p[blank], p[l]);
+    loc[index] = l;
+}
+
+hipError_t launch_gather_compact_rowmajor(hipStream_t stream, const float* xs, const int* ys, const unsigned* xn,
+                                          const unsigned* yn, float* gather_xs, int64_t* loc, const unsigned* mem_pref,
+                                          const unsigned* label_pref, unsigned N, unsigned T, unsigned U, unsigned V,
+                                          unsigned blank) {
+    if (N == 0 || T == 0 || U == 0) return hipSuccess;
+    const unsigned long long tiles = ((unsigned long long)T * U + 255ull) / 256ull;
+    if (tiles >= (1ull << 31) || N > 65535u) return hipErrorInvalidValue;
+    k_gather_compact_rowmajor<<<dim3((unsigned)tiles, N), 256, 0, stream>>>(
+        xs, ys, xn, yn, reinterpret_cast<float2*>(gather_xs), loc, mem_pref, label_pref, V, blank);
+    return hipGetLastError();
+}
+
 // Prefix sums and launch bounds of a compact batch in ONE launch (the reference's binding does this
 // with a chain of torch ops and four host synchronisations, binding.cpp:139-170):
 //   cell_offsets[0..N] = exclusive sums of xn*(yn+1) (int64), label_offsets[0..N] = exclusive sums of yn,

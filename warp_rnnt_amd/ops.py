@@ -98,8 +98,26 @@ def expand_grads(grads_diagonal, labels, xn, yn, grad_costs, V, blank, overwrite
     return out
 
 
+def _native_binding():
+    """warp_rnnt._C_native when it has been built (one compiled call instead of ctypes marshalling)."""
+    global _NATIVE
+    if _NATIVE is False:
+        try:
+            from warp_rnnt import _C as _wc
+            _NATIVE = _wc._native
+        except ImportError:
+            _NATIVE = None
+    return _NATIVE
+
+
+_NATIVE = False
+
+
 def log_softmax(x, out=None):
     """Row-wise log-softmax over the last axis (fp32, contiguous, GPU). ``out`` may be ``x``."""
+    nb = _native_binding()
+    if nb is not None:
+        return nb.log_softmax(x, out)
     L = _lib.load()
     assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous()
     if out is None:
