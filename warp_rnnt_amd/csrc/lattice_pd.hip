@@ -93,7 +93,6 @@ struct alignas(16) Smem {
     int exps[VSLOTS][WAVE];
     unsigned mail_in[MSLOTS][GPITCH];       // left neighbour's boundary column, as its granule payloads
     unsigned mail_out[MSLOTS][GPITCH];      // this block's boundary column: [0,16) X, [16] exponent
-    double zeros[K];                        // what every lane but lane 0 reads instead of mail_in
     double dumpx[WAVE][2];                  // where the other 63 lanes put their copy of the boundary column
     int dumpe[WAVE];
 };
@@ -109,6 +108,14 @@ __device__ __forceinline__ double wave_shr1_f64(double src) {
     const u64 b = __builtin_bit_cast(u64, src);
     const int lo = __builtin_amdgcn_mov_dpp((int)b, 0x138, 0xf, 0xf, true);
     const int hi = __builtin_amdgcn_mov_dpp((int)(b >> 32), 0x138, 0xf, 0xf, true);
+    return __builtin_bit_cast(double, ((u64)(unsigned)hi << 32) | (unsigned)lo);
+}
+// Lane i receives src from lane i-1; lane 0 keeps `first` (DPP "old" operand, bound_ctrl off: no extra instruction
+// when `first` dies here and the destination takes its registers).
+__device__ __forceinline__ double wave_shr1_f64_seed(double first, double src) {
+    const u64 b = __builtin_bit_cast(u64, src), f = __builtin_bit_cast(u64, first);
+    const int lo = __builtin_amdgcn_update_dpp((int)f, (int)b, 0x138, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp((int)(f >> 32), (int)(b >> 32), 0x138, 0xf, 0xf, false);
     return __builtin_bit_cast(double, ((u64)(unsigned)hi << 32) | (unsigned)lo);
 }
 // Lane i receives src from lane i-1; lane 0 receives `first`.
@@ -153,17 +160,18 @@ __device__ __forceinline__ void compute_block(const Cell2 (&cur)[K], Cell2 (&nxt
 #pragma unroll
     for (int k = 0; k < K; ++k) {
         const double xin = X;                             // what the right neighbour reads at this step
-        const double xl = wave_shr1_f64(X);
+        // the left neighbour's value: the lane to the left, or -- lane 0 of a column block that has a neighbour --
+        // the boundary column that neighbour published (its scale is in lane 0's factor c)
+        double xl;
+        if constexpr (SEED) xl = wave_shr1_f64_seed(seed[k], X);
+        else xl = wave_shr1_f64(X);
         double val;
         if constexpr (BETA) {
             // beta[t,u] = beta[t+1,u]*pB[t,u] + beta[t,u+1]*pL[t,u]: both weights belong to the receiving cell
-            const double w = cur[k].l * c;
-            val = __builtin_fma(xl, w, Y * cur[k].b);
-            if constexpr (SEED) val = __builtin_fma(seed[k], w, val);
+            val = __builtin_fma(xl, cur[k].l * c, Y * cur[k].b);
         } else {
             // alpha[t,u] = alpha[t-1,u]*pB[t-1,u] + alpha[t,u-1]*pL[t,u-1]: Y and X carry the products
             val = __builtin_fma(xl, c, Y);
-            if constexpr (SEED) val = __builtin_fma(seed[k], c, val);
         }
         double Yn, Xn;
         if constexpr (BETA) { Yn = val; Xn = val; }
@@ -498,11 +506,14 @@ __device__ __forceinline__ void sweep(const LatticeArgs& a, const Item it, const
         double seed[K];
         int e_mail = 0;
         if constexpr (has_left) {
-            // lane 0 reads the left neighbour's boundary column (staged by the loader one interval ago), every
-            // other lane reads zeros: the seed term of the step then needs no predicate
-            const double* mp = (lane == 0) ? reinterpret_cast<const double*>(&sm.mail_in[lb & (MSLOTS - 1)][0]) : &sm.zeros[0];
+            // the left neighbour's boundary column, staged by the loader one interval ago (every lane reads it -- one
+            // broadcast LDS access per pair -- only lane 0 uses it)
+            const f64x2* mp = reinterpret_cast<const f64x2*>(&sm.mail_in[lb & (MSLOTS - 1)][0]);
 #pragma unroll
-            for (int k = 0; k < K; ++k) seed[k] = mp[k];
+            for (int k = 0; k < K; k += 2) {
+                const f64x2 two = mp[k >> 1];
+                seed[k] = two.x; seed[k + 1] = two.y;
+            }
             e_mail = (int)sm.mail_in[lb & (MSLOTS - 1)][16];
         }
         const float* next_probs = &sm.probs[(lb + 1) & (PSLOTS - 1)][lane * PSTRIDE];
@@ -522,7 +533,6 @@ __device__ __forceinline__ void sweep(const LatticeArgs& a, const Item it, const
 #undef RNNT_PD_CALL
         block_barrier();
     };
-    if (lane < K) sm.zeros[lane] = 0.0;                    // before the first barrier
     int g = 0;
     for (; g < 1 + DLOAD; ++g) block_barrier();            // the loader converts block lo during interval DLOAD
     {
