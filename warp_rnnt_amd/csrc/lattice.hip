@@ -450,14 +450,17 @@ hipError_t launch_lattice(hipStream_t stream, const LatticeArgs& a, int N, int l
         // Long lattices of small batches: probability-domain sweep, one workgroup per 64-column block
         // (lattice_pd.hip), followed by the log-domain kernel for the (utterance, direction) pairs whose inputs it
         // flagged -- normally none: those workgroups return at once.  Where it pays, measured on MI355X
-        // (tools/lattice_probe.py, T=1500): its column blocks want a CU each, so up to ~320 workgroups
-        // (N <= 32 at U=300: 145-160 us against 168 us; N=48: 204 against 184), and its fixed costs (a memset node,
-        // a second launch, the hand-over lag between column blocks) are only recovered on long sweeps
-        // (T=400,U=100: 47 against 42 us; T=1500,U=64: 79 against 95 us).  U <= 512 because the log-domain kernel
-        // behind it must be able to redo a sweep.  RNNT_LATTICE=logdomain|pd overrides the choice (A/B runs).
+        // (tools/lattice_probe.py, us per alpha+beta sweep, probability domain / log domain):
+        //   N=16: T=1500 U=64 76/95, U=300 125/168, U=512 161/210; T=3000 U=500 (N=8) 224/376; T=700 U=100 57/63;
+        //         T=900 U=64 53/62; but T=400 U=100 43/42, T=500 U=300 85/76 (the hand-over lag between the column
+        //         blocks and the extra launches are only recovered on long sweeps);
+        //   T=1500 U=300: N=32 144/171, N=40 178/178, N=48 195/184, N=64 288/211 (its column blocks want a CU each).
+        // U <= 512 because the log-domain kernel behind it must be able to redo a sweep.
+        // RNNT_LATTICE=logdomain|pd overrides the choice (A/B runs, tests).
         static const char* force = getenv("RNNT_LATTICE");
         const int nA = (a.U + WAVE - 1) / WAVE;
-        bool use_pd = a.redo && a.queue && !is_compact(a) && nA <= 8 && (long long)2 * N * nA <= 320 && a.T + a.U >= 1024;
+        bool use_pd = a.redo && a.queue && !is_compact(a) && nA <= 8 && (long long)2 * N * nA <= 384 && a.T >= 640 &&
+                      a.T >= 2 * a.U;
         if (force && force[0] == 'l') use_pd = false;
         if (force && force[0] == 'p') use_pd = a.redo && a.queue && !is_compact(a) && nA <= 8;
         if (use_pd) {

@@ -48,7 +48,6 @@
 // Reference counterpart: core_gather.cu:37-133 (alphas), :135-234 (betas) -- 32x1 warp tiles ordered by
 // global spin locks, lse per cell.  Outputs are the same quantities (log alpha, log beta, fp32).
 #include <atomic>
-#include <cstdlib>
 #include <random>
 #include <type_traits>
 
@@ -621,31 +620,12 @@ hipError_t launch_lattice_pd(hipStream_t stream, const LatticeArgs& a0, int N) {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     const dim3 grid(2 * N * nA), block(5 * WAVE);
-    // One workgroup per CU while there are CUs to spare: the dispatcher otherwise packs several of these small
-    // workgroups onto one CU (five fit by LDS) and their waves share its four SIMDs again.  Claiming more than half
-    // of the CU's LDS is the only placement control there is.
-    static const size_t pad_env = getenv("RNNT_PD_LDS_PAD") ? (size_t)atol(getenv("RNNT_PD_LDS_PAD")) : (size_t)-1;
-    size_t pad = 0;
-    if (pad_env != (size_t)-1) pad = pad_env;
-    else if (grid.x <= 256) pad = 84 * 1024 - sizeof(pd::Smem);
-    if (pad > 32 * 1024) {   // > 64 KiB in total needs the opt-in
-        static std::atomic<bool> attr_set[2][64];
-        int dev = -1;
-        if (hipGetDevice(&dev) != hipSuccess) dev = -1;
-        const int ci = a.offs ? 1 : 0;
-        const bool tracked = dev >= 0 && dev < 64;
-        if (!tracked || !attr_set[ci][dev].load(std::memory_order_acquire)) {
-            const void* fn = a.offs ? reinterpret_cast<const void*>(&pd::k_lattice_pd<true>)
-                                    : reinterpret_cast<const void*>(&pd::k_lattice_pd<false>);
-            e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-            if (e != hipSuccess) return e;
-            if (tracked) attr_set[ci][dev].store(true, std::memory_order_release);
-        }
-    }
+    // (Forcing one workgroup per CU -- by claiming more than half of a CU's LDS -- was measured: no difference at
+    // 160 workgroups, the dispatcher spreads them already.)
     if (a.offs)
-        pd::k_lattice_pd<true><<<grid, block, pad, stream>>>(a, nA);
+        pd::k_lattice_pd<true><<<grid, block, 0, stream>>>(a, nA);
     else
-        pd::k_lattice_pd<false><<<grid, block, pad, stream>>>(a, nA);
+        pd::k_lattice_pd<false><<<grid, block, 0, stream>>>(a, nA);
     return hipGetLastError();
 }
 
