@@ -1,33 +1,44 @@
 #!/bin/bash
-# Runs on the GPU box (via gpurun): benches + rocprofv3 passes; leaves everything under gpurun_out/r01/.
-# Copy the summaries into profiles/ afterwards with tools/summarise_profiles.py.
+# Runs on the GPU box (via gpurun): benches + rocprofv3 passes; leaves everything under gpurun_out/$TAG/.
+# Copy the summaries into profiles/ afterwards with `python tools/summarise_profiles.py $TAG`.
+#   --pmc passes are separate from each other and never combined with other trace domains.
 set -u
+TAG=${1:-r02}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-OUT=$R/gpurun_out/r01
+OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 python $R/bench.py > $OUT/bench_c4.json 2> $OUT/bench_c4.err
-python $R/bench.py --config c2 --steps 200 > $OUT/bench_c2.json 2>> $OUT/bench.err
+python $R/bench.py --config c2 --steps 500 --warmup 20 > $OUT/bench_c2.json 2>> $OUT/bench.err
 python $R/bench.py --config c3 --steps 100 > $OUT/bench_c3.json 2>> $OUT/bench.err
 python $R/bench.py --config c5 --steps 5 --warmup 1 --no-cpu-baseline > $OUT/bench_c5.json 2>> $OUT/bench.err
-rocprofv3 --kernel-trace --stats -d $OUT/stats_c4 -o c4 -- python $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline > $OUT/bench_c4_profiled.json 2>/dev/null
-rocprofv3 --kernel-trace --stats -d $OUT/stats_c3 -o c3 -- python $R/bench.py --config c3 --steps 20 --warmup 3 --no-cpu-baseline > /dev/null 2>&1
-rocprofv3 --kernel-trace --stats -d $OUT/stats_c2 -o c2 -- python $R/bench.py --config c2 --steps 50 --warmup 3 --no-cpu-baseline > /dev/null 2>&1
+RNNT_LATTICE=logdomain python $R/bench.py --no-cpu-baseline > $OUT/bench_c4_logdomain_lattice.json 2>> $OUT/bench.err
+rocprofv3 --kernel-trace --stats -d $OUT/stats_c4 -o c4 -- python $R/bench.py --steps 50 --warmup 5 --no-cpu-baseline > $OUT/bench_c4_profiled.json 2>/dev/null
+rocprofv3 --kernel-trace --stats -d $OUT/stats_c3 -o c3 -- python $R/bench.py --config c3 --steps 50 --warmup 5 --no-cpu-baseline > /dev/null 2>&1
+rocprofv3 --kernel-trace --stats -d $OUT/stats_c2 -o c2 -- python $R/bench.py --config c2 --steps 100 --warmup 5 --no-cpu-baseline > /dev/null 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -o c4 -- python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -o c4 -- python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline > /dev/null 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch_c3 -o c3 -- python $R/bench.py --config c3 --steps 10 --warmup 2 --no-cpu-baseline > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write_c3 -o c3 -- python $R/bench.py --config c3 --steps 10 --warmup 2 --no-cpu-baseline > /dev/null 2>&1
 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU --kernel-trace --output-format csv -d $OUT/pmc_sq1 -o c4 -- python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline > /dev/null 2>&1
 rocprofv3 --pmc SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_SCA --kernel-trace --output-format csv -d $OUT/pmc_sq2 -o c4 -- python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline > /dev/null 2>&1
-for l in warp-rnnt warp-rnnt-gather warp-rnnt-compact warp-rnnt-fused; do
-  timeout 300 python $R/tools/benchmark_table.py --loss $l --markdown $OUT/table_$l.md > $OUT/table_$l.log 2>&1
-done
-# cache / memory counters of the loss kernels (gather, lattice, gradients), one --pmc pass per counter group
-i=0
-for set in "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum" "TCC_REQ_sum TCC_HIT_sum TCC_MISS_sum" \
-           "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum GRBM_GUI_ACTIVE" "TA_BUSY_avr TA_TA_BUSY_sum TCP_TA_TCP_STATE_READ_sum" \
-           "TCC_TAG_STALL_sum TCC_EA0_RDREQ_DRAM_sum TCC_BUSY_avr"; do
-  i=$((i+1))
-  rocprofv3 --pmc $set --kernel-trace --output-format csv -d $OUT/pmc_gather$i -o g -- python $R/tools/gather_probe.py $R/warp_rnnt_amd/libwarp_rnnt_amd.so > /dev/null 2>&1
+cd $R
+# parity at BASELINE sizes: the shipped build, the same with the log-domain lattice kernels only, and the libm build
+rm -f $OUT/parity_errors.json
+RNNT_PARITY_TABLE=$OUT/parity_errors.json RNNT_PARITY_BUILD="default (probability-domain lattice for c4/c5)" python -m pytest tests/test_gpu_baseline_sizes.py -q > $OUT/parity_default.log 2>&1
+RNNT_LATTICE=logdomain RNNT_PARITY_TABLE=$OUT/parity_errors.json RNNT_PARITY_BUILD="log-domain lattice, hardware exp2/log2 lse (RNNT_LATTICE=logdomain)" python -m pytest tests/test_gpu_baseline_sizes.py -q > $OUT/parity_logdomain.log 2>&1
+WARP_RNNT_AMD_LIB=$R/warp_rnnt_amd/libwarp_rnnt_amd_precise.so RNNT_PARITY_TABLE=$OUT/parity_errors.json RNNT_PARITY_BUILD="log-domain lattice, libm expf/log1pf (-DRNNT_PRECISE_LIBM)" python -m pytest tests/test_gpu_baseline_sizes.py -q > $OUT/parity_precise.log 2>&1
+# lattice kernel alone, both arithmetic domains
+python tools/lattice_probe.py pd2: > /dev/null 2>&1
+for sh in 16,1500,300 16,1500,64 16,1500,512 8,3000,500 32,1500,300 64,1500,300 16,700,100 16,400,100 16,150,40; do
+  for v in pd logdomain; do
+    RNNT_LATTICE=$v python tools/lattice_probe.py --shape $sh pd2: 2>&1 | grep median | sed "s/^pd2 */N,T,U=$sh lattice=$v  /"
+  done
+done > $OUT/lattice_probe.txt
+tools/ubench/pd_steps > $OUT/ubench_pd_steps.txt 2>&1
+python tools/host_overhead.py 2>&1 | grep -v amdgpu > $OUT/host_overhead.txt
+(echo "== ctypes fallback"; WARP_RNNT_AMD_NO_NATIVE_BINDING=1 python tools/host_overhead.py 2>&1 | grep -v amdgpu) >> $OUT/host_overhead.txt
+for l in warp-rnnt-gather warp-rnnt-fused; do
+  timeout 200 python $R/tools/benchmark_table.py --loss $l --markdown $OUT/table_$l.md > $OUT/table_$l.log 2>&1
 done
 ls $OUT

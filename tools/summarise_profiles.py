@@ -10,9 +10,9 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SRC = os.path.join(ROOT, "gpurun_out", "r01")
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r02"
+SRC = os.path.join(ROOT, "gpurun_out", TAG)
 DST = os.path.join(ROOT, "profiles")
-TAG = sys.argv[1] if len(sys.argv) > 1 else "r01"
 
 
 def pmc_summary(dirs, out):
@@ -48,6 +48,10 @@ def main():
         pmc_summary([f"pmc_gather{i}" for i in range(1, 6)], os.path.join(DST, f"{TAG}_rocprof_c4_pmc_gather_path.csv"))
     for f in glob.glob(os.path.join(SRC, "table_*.md")):
         shutil.copy(f, os.path.join(DST, f"{TAG}_" + os.path.basename(f)))
+    for name in ("parity_errors.json", "lattice_probe.txt", "ubench_pd_steps.txt", "host_overhead.txt",
+                 "bench_c4_logdomain_lattice.json"):
+        if os.path.exists(os.path.join(SRC, name)):
+            shutil.copy(os.path.join(SRC, name), os.path.join(DST, f"{TAG}_" + name))
     # HBM traffic of the dominant kernel, per launch (FETCH_SIZE doubled for wide coalesced reads)
     agg3 = pmc_summary(["pmc_fetch_c3", "pmc_write_c3"], os.path.join(DST, f"{TAG}_rocprof_c3_pmc_hbm.csv"))
     doc = {"_about": "HBM bytes per launch of the log-softmax kernel from rocprofv3 --pmc FETCH_SIZE / "
@@ -60,7 +64,9 @@ def main():
         (kname, f_kib), (_, w_kib) = pick("FETCH_SIZE"), pick("WRITE_SIZE")
         if f_kib is not None and w_kib is not None:
             doc[cfg] = {"kernel": kname, "fetch_size_kib": f_kib, "write_size_kib": w_kib,
-                        "traffic_bytes": f_kib * 2048 + w_kib * 1024}
+                        "traffic_bytes": f_kib * 2048 + w_kib * 1024,
+                        "source": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/collect_profiles.sh {TAG} "
+                                  f"(profiles/{TAG}_rocprof_{cfg}_pmc_hbm.csv)"}
     json.dump(doc, open(os.path.join(DST, "hbm_traffic.json"), "w"), indent=1)
     # bench.py reads hbm_traffic.json at run time, i.e. the file of the PREVIOUS collection; fill a missing
     # `roofline.traffic` from the PMC passes of this same collection

@@ -308,7 +308,12 @@ __device__ __forceinline__ void sweep(const LatticeArgs& a, const int n, Smem* s
         float* vslot = &sm.vals[lb & (VSLOTS - 1)][0][lane];
         const bool has_right = idx + 1 < nwa;
         float* mail_slot = (lane == WAVE - 1) ? &sm.mail[d0 & (RING - 1)] : &sm.trash[lane];
-        const bool full = (d0 >= wave_c + WAVE - 1) && (d0 + K <= wave_c + Tn) && (wave_c + WAVE <= Un);
+        // every lane that owns a lattice column live for the whole block?  Lanes beyond the last column (last column
+        // block of a lattice whose width is not a multiple of 64) run the unpredicated code as well: their values
+        // only travel to the right, to other such lanes, and the I/O wave drops their stores (voffset = OOB).
+        // Otherwise that column block -- the slowest link of the chain -- would run the predicated step for the
+        // whole sweep.
+        const bool full = (d0 >= min(wave_c + WAVE - 1, Un - 1)) && (d0 + K <= wave_c + Tn);
         if (full) {
             if (has_right) compute_block<BETA, false, true>(cur, mvec, Y, X, d0, ucol_chk, Tn, vslot, mail_slot);
             else compute_block<BETA, false, false>(cur, mvec, Y, X, d0, ucol_chk, Tn, vslot, mail_slot);
