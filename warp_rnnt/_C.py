@@ -15,8 +15,9 @@ try:                     # the compiled binding (warp_rnnt_amd/csrc/binding.cpp,
     from . import _C_native as _native
 except ImportError:      # not built: the ctypes path below does the same work, a few tens of microseconds slower
     _native = None
-if os.environ.get("WARP_RNNT_AMD_NO_NATIVE_BINDING"):
-    _native = None
+if os.environ.get("WARP_RNNT_AMD_NO_NATIVE_BINDING") or os.environ.get("WARP_RNNT_AMD_LIB"):
+    _native = None       # (the compiled module is linked against the in-tree library; another build of the C ABI --
+                         #  the A/B variants of _build.VARIANTS -- is reached through the ctypes loader)
 
 
 def _check_contiguous(x, name):
