@@ -44,7 +44,10 @@ def main():
     rng = np.random.RandomState(5)
     shapes = [(3, t, u) for u in (2, 31, 63, 64, 65, 127, 128, 129, 200) for t in (1, 2, 7, 8, 9, 33)]
     shapes += [(2, 20, 511), (2, 20, 512), (2, 257, 300), (1, 40, 320), (4, 150, 40), (2, 300, 257), (2, 70, 1),
-               (5, 7, 5), (2, 3, 70), (2, 90, 200)]
+               (5, 7, 5), (2, 3, 70), (2, 90, 200),
+               # a last column block of ONE column, deep into the lattice (its left neighbour's exponent is in the
+               # thousands by then): found by tools/fuzz_parity.py
+               (2, 227, 449), (2, 400, 193), (1, 300, 65), (2, 200, 66)]
     for i, (N, T, U) in enumerate(shapes):
         V = int(rng.choice([2, 3, 5, 9])) if U > 1 else 3
         logits, labels, xn, yn = make_case(2000 + i, N, T, U, V, ragged=bool(i % 2))

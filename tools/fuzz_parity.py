@@ -115,7 +115,7 @@ def main():
         wn = w.cpu().numpy().astype(np.float64)
         exact_cache = {}
 
-        def exact():      # fp64 restatement on the same fp32 log-probs (collision-free cases only)
+        def exact():      # fp64 restatement on the same fp32 log-probs (dense "label overwrites blank" rule on collisions)
             if "g" not in exact_cache:
                 from oracle import transduce_np
                 exact_cache["g"] = transduce_np.transduce_batch(lp.astype(np.float64), c["labels"], c["xn"], c["yn"],
@@ -124,8 +124,7 @@ def main():
 
         # 1. native dense op (grads computed in forward, overwrite rule on collisions)
         costs, grads = core.rnnt_loss(tl, ty, tx, tyn, blank=blank, fastemit_lambda=lam)
-        check("_C.rnnt_loss dense", c, costs.cpu().numpy(), grads.cpu().numpy(), ref["costs"], ref["grads"],
-              None if collide else exact)
+        check("_C.rnnt_loss dense", c, costs.cpu().numpy(), grads.cpu().numpy(), ref["costs"], ref["grads"], exact)
 
         # 2. wrapper, gather=True, backward with per-utterance weights (scatter-add rule on collisions)
         if not collide:

@@ -256,10 +256,13 @@ __device__ __forceinline__ void sweep(const LatticeArgs& a, const Item it, const
     // -- to other such lanes --, their stores are dropped by the buffer bounds check (voffset = OOB) and the input
     // check ignores them.  Without this the last column block would run the predicated paths for the whole sweep
     // and, being the slowest link of the chain, set the pace (T=1500: 305 us at U=300 against 130 us at U=128).
+    // (started BEFORE the block, d0 > last_col: a column that starts in the block takes its exponent from its
+    // left neighbour in the predicated renormalisation -- found by tools/fuzz_parity.py on lattices whose last
+    // column block holds a single column: its factor 2^(E_left - 0) underflowed fp64 and the sweep went to zero.)
     const int last_col = min(wave_c + WAVE - 1, Un - 1);
     auto full_block = [&](const int lb) {
         const int d0 = lb * K;
-        return (d0 >= last_col) && (d0 + K <= wave_c + Tn);
+        return (d0 > last_col) && (d0 + K <= wave_c + Tn);
     };
     // hand-over rings in global memory: one per (sweep, column-block boundary)
     const size_t sweep_id = (size_t)2 * n + (BETA ? 1 : 0);
@@ -401,7 +404,7 @@ __device__ __forceinline__ void sweep(const LatticeArgs& a, const Item it, const
         int p = lo - DLOAD;                                // interval index = p - (lo - DLOAD)
         const int p_end = hi + 1;                          // last conversion at hi-1, last staging (block hi-1) at hi
         // steady range: both activities live and every lane live (no predicates), p = 0 (mod NBR) at its start
-        int ps0 = max(lo + 1, (last_col + K - 1) / K);     // (lo + 1: the neighbour's block p-1 >= lo)
+        int ps0 = max(lo + 1, last_col / K + 1);           // (lo + 1: the neighbour's block p-1 >= lo)
         ps0 += (NBR - ((ps0 % NBR) + NBR) % NBR) % NBR;
         int ps1 = min(hi - DLOAD, (wave_c + Tn) / K);      // exclusive: blocks [.., ps1) are full
         if (has_left) ps1 = min(ps1, hi_left - 1);         // and the neighbour's block p+1 < hi_left
@@ -482,7 +485,7 @@ __device__ __forceinline__ void sweep(const LatticeArgs& a, const Item it, const
         for (; g < 3 + DLOAD; ++g) block_barrier();         // values of block lo exist after interval 4
         int p = lo + 3;
         const int p_end = hi + 3;
-        const int ps0 = max(lo, (last_col + K - 1) / K) + 3;
+        const int ps0 = max(lo, last_col / K + 1) + 3;
         const int ps1 = min(hi, (wave_c + Tn) / K) + 3;    // exclusive
         for (; p < p_end && p < ps0; ++p) s_step(p, std::true_type{});
         for (; p < ps1; ++p) s_step(p, std::false_type{});
