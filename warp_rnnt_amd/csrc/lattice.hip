@@ -459,7 +459,7 @@ hipError_t launch_lattice(hipStream_t stream, const LatticeArgs& a, int N, int l
         // RNNT_LATTICE=logdomain|pd overrides the choice (A/B runs, tests).
         static const char* force = getenv("RNNT_LATTICE");
         const int nA = (a.U + WAVE - 1) / WAVE;
-        bool use_pd = a.redo && a.queue && !is_compact(a) && nA <= 8 && (long long)2 * N * nA <= 384 && a.T >= 640 &&
+        bool use_pd = a.redo && a.queue && !is_compact(a) && nA <= 8 && (long long)2 * N * nA <= 256 && a.T >= 640 &&
                       a.T >= 2 * a.U;
         if (force && force[0] == 'l') use_pd = false;
         if (force && force[0] == 'p') use_pd = a.redo && a.queue && !is_compact(a) && nA <= 8;

@@ -58,18 +58,24 @@ namespace rnnt {
 
 namespace pd {
 
-constexpr int K = 8;             // diagonals per block (= renormalisation interval)
+#ifndef RNNT_PD_K
+#define RNNT_PD_K 16
+#endif
+constexpr int K = RNNT_PD_K;     // diagonals per block (one s_barrier, one hand-over per block)
+constexpr int KR = 8;            // diagonals between renormalisations
+constexpr int NH = K / KR;       // renormalisations ("halves") per block
+static_assert(K % KR == 0 && (K == 8 || K == 16), "block = one or two renormalisation intervals");
 constexpr int KH = K / 2;        // diagonals per block and helper wave
 constexpr int PSLOTS = 2;        // LDS ring of probability blocks
 constexpr int VSLOTS = 2;        // LDS ring of value blocks
 constexpr int MSLOTS = 2;        // LDS rings of boundary-column blocks (incoming and outgoing)
 constexpr int DLOAD = 2;         // the loader issues its HBM loads this many blocks before it converts them
 constexpr int NBR = DLOAD + 1;   // its register ring
-constexpr int PSTRIDE = 36;      // dwords per lane per probability slot: 8 cells x (pB,pL) fp64 = 32, +4: the
+constexpr int PSTRIDE = 4 * K + 4;      // dwords per lane per probability slot: 8 cells x (pB,pL) fp64 = 32, +4: the
                                  // 16-lane groups of ds_read/write_b128 then cover all 64 banks (MI355X_MICROARCH.md)
-constexpr int VSTRIDE = 20;      // dwords per lane per value slot: 8 fp64 = 16, +4 (same reason)
-constexpr int GRAN = 17;         // granules per block: 16 dwords of lane 63's X on entry to the 8 steps + its exponent
-constexpr int GPITCH = 32;       // granules reserved per block in the global ring (256 bytes)
+constexpr int VSTRIDE = 2 * K + 4;      // dwords per lane per value slot: 8 fp64 = 16, +4 (same reason)
+constexpr int GRAN = 2 * K + NH;         // granules per block: 16 dwords of lane 63's X on entry to the 8 steps + its exponent
+constexpr int GPITCH = 4 * K;       // granules reserved per block in the global ring (256 bytes)
 constexpr int RSRC_WORD3 = 0x00020000;
 constexpr int OOB = (int)0x80000000;
 constexpr float P_MIN = 0x1p-115f, P_MAX = 0x1p100f;   // accepted range of an fp32 probability (see header)
@@ -77,7 +83,7 @@ constexpr float LOG2E = 1.44269504088896340736f;
 constexpr float LN2 = 0.693147180559945309417f;
 constexpr int SPIN_LIMIT = 1 << 21;                      // polls before a hand-over is declared lost
 #ifndef RNNT_PD_LAG
-#define RNNT_PD_LAG 3
+#define RNNT_PD_LAG 1
 #endif
 constexpr int LAG = RNNT_PD_LAG; // blocks a column block lets its left neighbour get ahead when it has caught up with it
 
@@ -89,7 +95,7 @@ typedef unsigned long long u64;
 struct alignas(16) Smem {
     float probs[PSLOTS][WAVE * PSTRIDE];    // [lane][k] (pB, pL) fp64
     float vals[VSLOTS][WAVE * VSTRIDE];     // [lane][k] fp64 value, scale 2^exps[lane]
-    int exps[VSLOTS][WAVE];
+    int exps[VSLOTS][NH][WAVE];          // one scale per renormalisation interval
     unsigned mail_in[MSLOTS][GPITCH];       // left neighbour's boundary column, as its granule payloads
     unsigned mail_out[MSLOTS][GPITCH];      // this block's boundary column: [0,16) X, [16] exponent
     double dumpx[WAVE][2];                  // where the other 63 lanes put their copy of the boundary column
@@ -133,31 +139,36 @@ struct Cell2 { double b, l; };   // blank / label probability of one lattice cel
 //   MAIL:   lane 63's X on entry to every step is recorded for the right neighbour
 template <bool BETA, bool MASKED, bool SEED, bool MAIL>
 __device__ __forceinline__ void compute_block(const Cell2 (&cur)[K], Cell2 (&nxt)[K], const double (&seed)[K],
-                                              const int e_mail, double& Y, double& X, int& E, const int d0,
-                                              const int ucol_chk, const int Tn, const int front,
-                                              const bool started_all, const bool lane_started,
+                                              const int e_mail0, const int e_mail1, double& Y, double& X, int& E,
+                                              const int d0, const int ucol_chk, const int Tn, const int wave_c,
                                               const float* next_probs, float* vdst, double* xdst, int* edst,
                                               int* email_dst) {
-    // ---- renormalisation (exact: powers of two) ----
-    const int e = __builtin_amdgcn_frexp_exp(Y);          // 0 for Y == 0
-    Y = __builtin_amdgcn_frexp_mant(Y);
-    X = __builtin_ldexp(X, -e);
-    E += e;
-    if constexpr (MASKED) {
-        // lanes that have not started adopt the exponent of the last started column (their first value
-        // arrives from it), or the mailbox's when the whole column block has not started
-        int ef;
-        if (front >= 0) ef = __builtin_amdgcn_readlane(E, front > WAVE - 1 ? WAVE - 1 : front);
-        else ef = SEED ? e_mail : __builtin_amdgcn_readlane(E, 0);
-        if (!started_all) E = lane_started ? E : ef;
-    }
-    *edst = E;                                            // the storer's scale for this block's values
-    if constexpr (MAIL) *email_dst = E;                   // (lane 63's pointer; the others aim at a dump slot)
-    const int e_left = wave_shr1_i32(SEED ? e_mail : E, E);
-    const double c = __builtin_ldexp(1.0, e_left - E);    // 2^(E_left - E_own); lane 0 of the first block: 1
-    double vprev = 0.0, xprev = 0.0;
+    double vprev = 0.0, xprev = 0.0, c = 1.0;
 #pragma unroll
     for (int k = 0; k < K; ++k) {
+        if (k % KR == 0) {
+            // ---- renormalisation (exact: powers of two), every KR diagonals ----
+            const int h = k / KR;
+            const int e = __builtin_amdgcn_frexp_exp(Y);      // 0 for Y == 0
+            Y = __builtin_amdgcn_frexp_mant(Y);
+            X = __builtin_ldexp(X, -e);
+            E += e;
+            const int e_mail_h = h ? e_mail1 : e_mail0;
+            if constexpr (MASKED) {
+                // lanes that have not started adopt the exponent of the last started column (their first value
+                // arrives from it), or the mailbox's when the whole column block has not started
+                const int front = d0 + k - 1 - wave_c;         // last lane that has started (may be < 0 or > 63)
+                const bool lane_started = (ucol_chk <= d0 + k - 1) || (ucol_chk == 0);
+                int ef;
+                if (front >= 0) ef = __builtin_amdgcn_readlane(E, front > WAVE - 1 ? WAVE - 1 : front);
+                else ef = SEED ? e_mail_h : __builtin_amdgcn_readlane(E, 0);
+                if (front < WAVE - 1) E = lane_started ? E : ef;
+            }
+            edst[h * WAVE] = E;                               // the storer's scale for this interval's values
+            if constexpr (MAIL) email_dst[h] = E;             // (lane 63's pointer; the others aim at a dump slot)
+            const int e_left = wave_shr1_i32(SEED ? e_mail_h : E, E);
+            c = __builtin_ldexp(1.0, e_left - E);             // 2^(E_left - E_own); lane 0 of the first block: 1
+        }
         const double xin = X;                             // what the right neighbour reads at this step
         // the left neighbour's value: the lane to the left, or -- lane 0 of a column block that has a neighbour --
         // the boundary column that neighbour published (its scale is in lane 0's factor c)
@@ -182,7 +193,7 @@ __device__ __forceinline__ void compute_block(const Cell2 (&cur)[K], Cell2 (&nxt
         } else {
             Y = Yn; X = Xn;
         }
-        // one cell of the next block per step (written by the loader one block ago, needed one block from
+        // one cell of the next block per step (written by the loaders one block ago, needed one block from
         // now; behind the last block this reads a stale slot that nobody uses)
         {
             const f64x2 pr = *reinterpret_cast<const f64x2*>(next_probs + 4 * k);
@@ -444,7 +455,7 @@ __device__ __forceinline__ void sweep(const LatticeArgs& a, const Item it, const
                     __hip_atomic_store(ring_out + (size_t)ps * GPITCH + lane, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
                 const float* src = &sm.vals[ps & (VSLOTS - 1)][lane * VSTRIDE + 2 * k0];
-                const int eb = sm.exps[ps & (VSLOTS - 1)][lane] - 1023;
+                const int eb = sm.exps[ps & (VSLOTS - 1)][k0 / KR][lane] - 1023;
                 int offs[K];
                 advance(row_st, rowb_out, offs);
                 const int d0 = ps * K + k0;
@@ -506,7 +517,7 @@ __device__ __forceinline__ void sweep(const LatticeArgs& a, const Item it, const
     auto do_block = [&](const int lb, const Cell2 (&cur)[K], Cell2 (&nxt)[K]) {
         const int d0 = lb * K;
         double seed[K];
-        int e_mail = 0;
+        int e_mail0 = 0, e_mail1 = 0;
         if constexpr (has_left) {
             // the left neighbour's boundary column, staged by the loader one interval ago (every lane reads it -- one
             // broadcast LDS access per pair -- only lane 0 uses it)
@@ -516,20 +527,18 @@ __device__ __forceinline__ void sweep(const LatticeArgs& a, const Item it, const
                 const f64x2 two = mp[k >> 1];
                 seed[k] = two.x; seed[k + 1] = two.y;
             }
-            e_mail = (int)sm.mail_in[lb & (MSLOTS - 1)][16];
+            e_mail0 = (int)sm.mail_in[lb & (MSLOTS - 1)][2 * K];
+            e_mail1 = (int)sm.mail_in[lb & (MSLOTS - 1)][2 * K + NH - 1];
         }
         const float* next_probs = &sm.probs[(lb + 1) & (PSLOTS - 1)][lane * PSTRIDE];
         float* vdst = &sm.vals[lb & (VSLOTS - 1)][lane * VSTRIDE];
-        int* edst = &sm.exps[lb & (VSLOTS - 1)][lane];
+        int* edst = &sm.exps[lb & (VSLOTS - 1)][0][lane];
         double* xdst = (lane == WAVE - 1) ? reinterpret_cast<double*>(&sm.mail_out[lb & (MSLOTS - 1)][0]) : &sm.dumpx[lane][0];
-        int* email_dst = (lane == WAVE - 1) ? reinterpret_cast<int*>(&sm.mail_out[lb & (MSLOTS - 1)][16]) : &sm.dumpe[lane];
+        int* email_dst = (lane == WAVE - 1) ? reinterpret_cast<int*>(&sm.mail_out[lb & (MSLOTS - 1)][2 * K]) : &sm.dumpe[lane];
         const bool full = full_block(lb);
-        const int front = d0 - 1 - wave_c;                 // last lane that has started (may be < 0 or > 63)
-        const bool lane_started = (ucol <= d0 - 1) || (ucol == 0);
-        const bool started_all = front >= WAVE - 1;
-#define RNNT_PD_CALL(MASKED, SEED, MAIL)                                                                           \
-    compute_block<BETA, MASKED, SEED, MAIL>(cur, nxt, seed, e_mail, Y, X, E, d0, ucol_chk, Tn, front, started_all, \
-                                            lane_started, next_probs, vdst, xdst, edst, email_dst)
+#define RNNT_PD_CALL(MASKED, SEED, MAIL)                                                                          \
+    compute_block<BETA, MASKED, SEED, MAIL>(cur, nxt, seed, e_mail0, e_mail1, Y, X, E, d0, ucol_chk, Tn, wave_c, \
+                                            next_probs, vdst, xdst, edst, email_dst)
         if (full) RNNT_PD_CALL(false, HAS_LEFT, HAS_RIGHT);
         else RNNT_PD_CALL(true, HAS_LEFT, HAS_RIGHT);
 #undef RNNT_PD_CALL
