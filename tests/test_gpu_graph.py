@@ -1,0 +1,97 @@
+"""The loss under HIP graph capture (torch.cuda.CUDAGraph): a captured call is enqueue-only, so it must replay,
+and every replay must see its own inputs.
+
+The probability-domain lattice hands boundary columns between workgroups through tagged granules in the workspace;
+the tag carries a launch epoch. Kernel arguments are frozen at capture time, so the epoch also needs a part that
+lives on the device (lattice_pd.hip: k_prepare) -- with a frozen epoch a replay accepts the granules the previous
+replay left behind. The shapes below take that kernel (T >= 640, T >= 2U) with two and three column blocks.
+
+No counterpart in the reference (its launches are capturable as well; it has no cross-workgroup hand-over)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _inputs(torch, N, T, U, V, seed):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    logits = torch.randn(N, T, U, V, generator=g) * 2.0
+    labels = torch.randint(1, V, (N, U - 1), generator=g, dtype=torch.int32)
+    xn = torch.randint(T // 2, T + 1, (N,), generator=g, dtype=torch.int32)
+    yn = torch.randint(U // 2, U, (N,), generator=g, dtype=torch.int32)
+    xn[0], yn[0] = T, U - 1
+    return torch.log_softmax(logits, -1), labels, xn, yn
+
+
+@pytest.mark.parametrize("shape", [(2, 700, 70, 11), (1, 900, 150, 7)])
+def test_native_op_replays_with_fresh_inputs(shape):
+    import torch
+    from warp_rnnt import _C
+    N, T, U, V = shape
+    dev = torch.device("cuda:0")
+    sets = [tuple(t.to(dev) for t in _inputs(torch, N, T, U, V, seed)) for seed in (1, 2, 3)]
+    eager = [_C.rnnt_loss_gather(*s, 0, 0.0) for s in sets]
+    torch.cuda.synchronize()
+
+    static = [t.clone() for t in sets[0]]
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(2):
+            _C.rnnt_loss_gather(*static, 0, 0.0)
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        costs, grads = _C.rnnt_loss_gather(*static, 0, 0.0)
+    for rep in range(12):
+        k = rep % len(sets)
+        for dst, src in zip(static, sets[k]):
+            dst.copy_(src)
+        graph.replay()
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(costs.cpu().numpy(), eager[k][0].cpu().numpy(),
+                                      err_msg=f"replay {rep} (input set {k})")
+        assert torch.equal(grads, eager[k][1]), f"replay {rep} (input set {k}): gradients differ from eager"
+
+
+def test_training_step_replays():
+    """forward + backward of warp_rnnt.rnnt_loss(gather=True) from logits, captured as one graph."""
+    import torch
+    import warp_rnnt
+    N, T, U, V = 2, 700, 70, 11
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device="cpu").manual_seed(5)
+    batches = [torch.randn(N, T, U, V, generator=g).to(dev) for _ in range(3)]
+    _, labels, xn, yn = (t.to(dev) for t in _inputs(torch, N, T, U, V, 7))
+
+    def step(logits):
+        lp = torch.log_softmax(logits, -1)
+        loss = warp_rnnt.rnnt_loss(lp, labels, xn, yn, reduction="mean", gather=True)
+        loss.backward()
+        return loss
+
+    want = []
+    for b in batches:
+        x = b.clone().requires_grad_(True)
+        want.append((step(x).detach().clone(), x.grad.clone()))
+
+    x = batches[0].clone().requires_grad_(True)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(2):
+            x.grad = None
+            step(x)
+    torch.cuda.current_stream().wait_stream(side)
+    x.grad = None
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        loss = step(x)
+    for rep in range(9):
+        k = rep % len(batches)
+        with torch.no_grad():
+            x.copy_(batches[k])
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(loss, want[k][0]), f"replay {rep}: loss {loss.item()} vs eager {want[k][0].item()}"
+        assert torch.equal(x.grad, want[k][1]), f"replay {rep}: d/d logits differ from eager"

@@ -32,7 +32,7 @@ size_t carve(void* base, int N, int T, int U, Workspace* w) {
     float* ws2 = reinterpret_cast<float*>(take(cells * 2 * sizeof(float)));
     float* ll = reinterpret_cast<float*>(take((size_t)N * sizeof(float)));
     int* mismatch = reinterpret_cast<int*>(take((size_t)N * sizeof(int)));
-    int* redo = reinterpret_cast<int*>(take(((size_t)N * 2 + 1) * sizeof(int)));
+    int* redo = reinterpret_cast<int*>(take(((size_t)N * 2 + 2) * sizeof(int)));   // flags, queue head, launch counter
     unsigned long long* mail = reinterpret_cast<unsigned long long*>(take(pd_mail_bytes(N, T, U)));
     if (w) *w = Workspace{alphas, betas, ws2, ll, mismatch, redo, mail};
     return off;

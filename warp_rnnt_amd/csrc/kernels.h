@@ -19,7 +19,8 @@ struct LatticeArgs {
     int* redo;            // (2N,) [2n+dir]: written by the probability-domain kernel (non-zero = inputs outside the
                           // range it can represent, or a lost hand-over), read by the log-domain kernel launched
                           // behind it (0 = nothing to do); nullptr = log-domain kernel only
-    int* queue;           // work-item counter of the probability-domain kernel; MUST be redo + 2N (zeroed together)
+    int* queue;           // work-item counter of the probability-domain kernel; MUST be redo + 2N (zeroed together);
+                          // queue[1] is its launch counter (never zeroed: any start value will do)
     unsigned long long* mail;  // its hand-over rings between column blocks (pd_mail_bytes), needed when U > 64
     int mail_blocks;      // filled in by launch_lattice_pd
     unsigned epoch;       // filled in by launch_lattice_pd

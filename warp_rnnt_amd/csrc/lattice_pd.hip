@@ -570,9 +570,14 @@ __device__ __forceinline__ void sweep(const LatticeArgs& a, const Item it, const
 }
 
 template <bool COMPACT>
-__global__ void __launch_bounds__(5 * WAVE) k_lattice_pd(const LatticeArgs a, const int nA) {
+__global__ void __launch_bounds__(5 * WAVE) k_lattice_pd(LatticeArgs a, const int nA) {
     __shared__ Smem sm;
     __shared__ int wg_bad, s_item;
+    // launch epoch = host counter (constant across the replays of a captured graph) + device counter (queue[1],
+    // bumped by k_prepare in front of every launch, replayed or not)
+#ifndef RNNT_PD_FROZEN_EPOCH      // (defined only to show that tests/test_gpu_graph.py fails without the counter)
+    a.epoch += (unsigned)a.queue[1];
+#endif
     // work items in column-block-major order from an atomic counter: the workgroup that holds item i knows that
     // every item < i -- in particular its left neighbour, item i - 2N -- is held by a workgroup that has started
     if (threadIdx.x == 0) { s_item = atomicAdd(a.queue, 1); wg_bad = 0; }
@@ -600,8 +605,12 @@ __global__ void __launch_bounds__(5 * WAVE) k_lattice_pd(const LatticeArgs a, co
     if (threadIdx.x == 0 && wg_bad) atomicOr(&a.redo[2 * it.n + it.dir], wg_bad);
 }
 
-__global__ void __launch_bounds__(256) k_zero_words(int* p, int n) {
+// Clears the redo flags and the queue head (n words) and bumps the launch counter behind them (p[n]).  The counter
+// lives in the workspace so that every REPLAY of a captured graph gets a fresh epoch too -- kernel arguments are
+// frozen at capture time, and with a frozen epoch the granules of the previous replay would validate.
+__global__ void __launch_bounds__(256) k_prepare(int* p, int n) {
     for (int i = threadIdx.x; i < n; i += 256) p[i] = 0;
+    if (threadIdx.x == 0) p[n] = p[n] + 1;
 }
 
 }  // namespace pd
@@ -614,21 +623,22 @@ size_t pd_mail_bytes(int N, int T, int U) {
     return (size_t)2 * N * (nA - 1) * pd_mail_blocks(T, U) * pd::GPITCH * sizeof(pd::u64);
 }
 
-// Needs a.redo, a.queue (and a.mail when U > 64); zeroes redo and the queue head itself (one memset node).
+// Needs a.redo, a.queue = a.redo + 2N with the launch counter behind it (and a.mail when U > 64); zeroes redo and
+// the queue head itself.
 hipError_t launch_lattice_pd(hipStream_t stream, const LatticeArgs& a0, int N) {
     if (N <= 0) return hipSuccess;
     const int nA = (a0.U + WAVE - 1) / WAVE;
     if (!a0.redo || !a0.queue || (nA > 1 && !a0.mail)) return hipErrorNotSupported;
     if ((long long)2 * N * nA >= (1ll << 31)) return hipErrorNotSupported;
     // launch epoch: granules of earlier launches (same buffer) never validate.  Random start so that a recycled
-    // allocation of another process does not either.
+    // allocation of another process does not either; the device-side counter (k_prepare) is added in the kernel.
     static std::atomic<unsigned> epoch{std::random_device{}()};
     LatticeArgs a = a0;
     a.epoch = epoch.fetch_add(1, std::memory_order_relaxed) + 1;
     a.mail_blocks = (int)pd_mail_blocks(a.T, a.U);
     // redo (2N ints) and the queue head are contiguous in the workspace (api.hip: carve).  One tiny kernel:
     // hipMemsetAsync of these few bytes becomes two fill kernels of ~5 us each.
-    pd::k_zero_words<<<1, 256, 0, stream>>>(a.redo, 2 * N + 1);
+    pd::k_prepare<<<1, 256, 0, stream>>>(a.redo, 2 * N + 1);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     const dim3 grid(2 * N * nA), block(5 * WAVE);
