@@ -210,6 +210,12 @@ rnntStatus_t rnnt_amd_gather(rnntStream_t stream, const float *log_probs, const 
 rnntStatus_t rnnt_amd_debug_lattice_only(rnntStream_t stream, void *workspace, const int *xn,
                                          const int *yn, int N, int T, int U);
 
+/* Diagnostics (tests/pd_vs_oracle.py): byte offset, inside the workspace, of the (2N,) int32 flags the
+ * probability-domain lattice kernel leaves for the log-domain kernel launched behind it: flags[2n+dir] != 0 means
+ * sweep `dir` (0 alpha, 1 beta) of utterance n was redone in the log domain (bit 0: an input outside the range
+ * the probability domain carries; bit 1: a hand-over between column blocks timed out). */
+size_t rnnt_amd_debug_redo_offset(int N, int T, int U);
+
 /* Library version, for the host-side loader. */
 int rnnt_amd_version(void);
 

@@ -28,6 +28,25 @@ def native(lp2, xn, yn, lam=0.0, want_mismatch=False):
     return [o.cpu().numpy() for o in out]
 
 
+def redo_flags(lp2, xn, yn):
+    """(2N,) flags the probability-domain kernel left for the log-domain one (include/warp_rnnt_amd.h:
+    rnnt_amd_debug_redo_offset), from a call on a workspace of our own."""
+    from warp_rnnt_amd import _lib, ops
+    L = _lib.load()
+    N, T, U, _ = lp2.shape
+    x, a, b = t32(lp2), t32(xn), t32(yn)
+    costs = torch.empty(N, device=x.device)
+    grads = torch.empty_like(x)
+    ws = torch.zeros(L.rnnt_amd_workspace_size(N, T, U), dtype=torch.uint8, device=x.device)
+    st = L.rnnt_amd_loss(torch.cuda.current_stream().cuda_stream, ws.data_ptr(), ops.IN_LOG_PROBS_GATHERED,
+                         x.data_ptr(), None, a.data_ptr(), b.data_ptr(), costs.data_ptr(), grads.data_ptr(),
+                         ops.GRADS_GATHERED, N, T, U, 2, 0, 0.0)
+    assert st == 0
+    torch.cuda.synchronize()
+    off = L.rnnt_amd_debug_redo_offset(N, T, U)
+    return ws[off:off + 8 * N].view(torch.int32).cpu().numpy()
+
+
 def check(name, lp2, xn, yn, lam=0.0, grad_atol=None):
     ref = oracle.rnnt_loss_f32(lp2, None, xn, yn, blank=-1, fastemit_lambda=lam, scan_mode=1)
     c, g = native(lp2, xn, yn, lam)
@@ -59,6 +78,12 @@ def main():
     for _ in range(2):
         # |log-likelihood| ~ 1e3: two fp32 implementations differ by a few 1e-4 there; the oracle is the looser one
         check("long 700x300", lp2, xn, yn, grad_atol=2e-3)
+    flags = redo_flags(lp2, xn, yn)
+    if os.environ.get("PD_VS_ORACLE_EXPECT_REDO"):
+        # the build whose hand-over waits give up at once: sweeps must have been flagged "hand-over lost" (bit 1)
+        assert (flags & 2).any(), flags
+    else:
+        assert not flags.any(), flags      # ordinary inputs, patient waits: nothing is redone
     # inputs the probability domain cannot carry: -inf, a log-prob below -80, +3e8 (the guard case of
     # test_gpu_parity.py) -- every one must come back exactly as the log-domain kernel computes it
     logits, labels, xn, yn = make_case(78, 4, 40, 70, 5)

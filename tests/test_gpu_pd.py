@@ -19,3 +19,18 @@ def test_forced_probability_domain_kernel_against_oracle():
                          stderr=subprocess.STDOUT, timeout=900)
     text = out.stdout.decode()
     assert out.returncode == 0 and "PD_VS_ORACLE_OK" in text, text[-4000:]
+
+
+def test_lost_hand_over_falls_back_to_log_domain_kernel():
+    """A hand-over wait is bounded; when it gives up, the sweep carries on with whatever the ring holds, is flagged
+    and redone by the log-domain kernel behind. The `short_spin` build gives up at the first poll, so every column
+    block that catches up with its neighbour takes that path; results must not change."""
+    from warp_rnnt_amd import _build
+    lib = _build.variant_path("short_spin")
+    if not os.path.exists(lib):
+        _build.build(variant="short_spin")
+    env = dict(os.environ, RNNT_LATTICE="pd", WARP_RNNT_AMD_LIB=lib, PD_VS_ORACLE_EXPECT_REDO="1")
+    out = subprocess.run([sys.executable, os.path.join(HERE, "pd_vs_oracle.py")], env=env, stdout=subprocess.PIPE,
+                         stderr=subprocess.STDOUT, timeout=900)
+    text = out.stdout.decode()
+    assert out.returncode == 0 and "PD_VS_ORACLE_OK" in text, text[-4000:]

@@ -33,6 +33,7 @@ SYMBOLS = {
     "rnnt_amd_compact_last_status": (_i, []),
     "rnnt_amd_workspace_size": (_sz, [_i, _i, _i]),
     "rnnt_amd_workspace_mismatch_offset": (_sz, [_i, _i, _i]),
+    "rnnt_amd_debug_redo_offset": (_sz, [_i, _i, _i]),
     "rnnt_amd_loss": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f]),
     "rnnt_amd_expand_grads": (_i, [_vp] * 7 + [_i] * 6),
     "rnnt_amd_logits_backward": (_i, [_vp] * 6 + [_i] * 5),

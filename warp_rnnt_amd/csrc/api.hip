@@ -64,6 +64,13 @@ size_t rnnt_amd_workspace_mismatch_offset(int N, int T, int U) {
     return reinterpret_cast<uintptr_t>(w.mismatch) - ALIGN;
 }
 
+size_t rnnt_amd_debug_redo_offset(int N, int T, int U) {
+    if (!dims_ok(N, T, U)) return 0;
+    Workspace w;
+    carve(reinterpret_cast<void*>(ALIGN), N, T, U, &w);
+    return reinterpret_cast<uintptr_t>(w.redo) - ALIGN;
+}
+
 rnntStatus_t run_warp_rnnt(rnntStream_t stream, unsigned int* counts, float* alphas, float* betas,
                            const int* labels, const float* log_probs, float* grads, float* costs,
                            const int* xn, const int* yn, int N, int T, int U, int V, int blank,

@@ -81,7 +81,11 @@ constexpr int OOB = (int)0x80000000;
 constexpr float P_MIN = 0x1p-115f, P_MAX = 0x1p100f;   // accepted range of an fp32 probability (see header)
 constexpr float LOG2E = 1.44269504088896340736f;
 constexpr float LN2 = 0.693147180559945309417f;
-constexpr int SPIN_LIMIT = 1 << 21;                      // polls before a hand-over is declared lost
+#ifndef RNNT_PD_SPIN_LIMIT
+#define RNNT_PD_SPIN_LIMIT (1 << 21)
+#endif
+constexpr int SPIN_LIMIT = RNNT_PD_SPIN_LIMIT;           // polls before a hand-over is declared lost (a few seconds;
+                                                         // the `short_spin` build variant sets 0: tests/test_gpu_pd.py)
 #ifndef RNNT_PD_LAG
 #define RNNT_PD_LAG 1
 #endif
@@ -339,11 +343,13 @@ __device__ __forceinline__ void sweep(const LatticeArgs& a, const Item it, const
             const bool ok = lane >= GRAN || (unsigned)(g >> 32) == block_tag(a.epoch, lb);
             return __builtin_amdgcn_ballot_w64(!ok) == 0;
         };
+        bool lost = false;     // a wait has timed out: the sweep is flagged for the log-domain kernel, the rest of it
+                               // runs on whatever the ring holds without waiting again
         auto mail_wait = [&](const int lb) {               // poll until block lb of the neighbour is there
             for (int spins = 0;; ++spins) {
                 const u64 g = mail_request(lb);
-                if (mail_valid(lb, g)) return g;
-                if (spins > SPIN_LIMIT) { *wg_bad = 2; return g; }   // producer lost: the log-domain kernel redoes the sweep
+                if (lost || mail_valid(lb, g)) return g;
+                if (spins >= SPIN_LIMIT) { *wg_bad = 2; lost = true; return g; }
                 __builtin_amdgcn_s_sleep(8);
             }
         };
