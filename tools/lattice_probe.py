@@ -2,6 +2,7 @@
 """A/B timing of the lattice kernel alone for several builds of the library.
 
     python tools/lattice_probe.py [--shape N,T,U] name1:-DFLAG1,-DFLAG2 name2: ...
+    python tools/lattice_probe.py [--shape N,T,U] main:        (the in-tree library, no build)
 
 Each variant is compiled (hipcc, extra flags) into its own shared object, loaded with ctypes and
 the alpha/beta sweep is timed with HIP events in interleaved rounds (median / min in us)."""
@@ -73,6 +74,8 @@ def main():
     grads = torch.empty((N, T, U, 2), device=dev)
     name, flags = variants[0]
     pre = os.path.join(ROOT, "tools", "_probe", name, "lib.so")
+    if name == "main":                      # the in-tree library as built by warp_rnnt_amd._build
+        pre = _lib.lib_path()
     if os.path.exists(pre):
         L = ctypes.CDLL(pre)
         for sym, (res, a_) in _lib.SYMBOLS.items():

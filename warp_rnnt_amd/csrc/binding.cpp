@@ -123,8 +123,18 @@ at::Tensor rnnt_loss_gather_backward(const at::Tensor& grad_costs, const at::Ten
                                      int64_t blank) {
     RNNT_CHECK_CONTIGUOUS(grad_costs); RNNT_CHECK_CONTIGUOUS(grads_diagonal);
     RNNT_CHECK_FLOAT(grad_costs); RNNT_CHECK_FLOAT(grads_diagonal);
+    RNNT_CHECK_CONTIGUOUS(ys); RNNT_CHECK_CONTIGUOUS(xn); RNNT_CHECK_CONTIGUOUS(yn);
+    RNNT_CHECK_INT(ys); RNNT_CHECK_INT(xn); RNNT_CHECK_INT(yn);
     RNNT_CHECK_CUDA(grads_diagonal);
     TORCH_CHECK(grads_diagonal.dim() == 4 && grads_diagonal.size(3) == 2, "grads_diagonal must be (N,T,U,2)");
+    for (const at::Tensor* t : {&grad_costs, &ys, &xn, &yn})
+        TORCH_CHECK(t->device() == grads_diagonal.device(), "all tensors must be on the device of grads_diagonal");
+    TORCH_CHECK(grad_costs.numel() == grads_diagonal.size(0) && xn.numel() == grads_diagonal.size(0) &&
+                yn.numel() == grads_diagonal.size(0), "grad_costs, xn, yn shape must be equal (N,)");
+    TORCH_CHECK(ys.numel() == grads_diagonal.size(0) * (grads_diagonal.size(2) - 1),
+                "ys shape (N, U-1) mismatched with grads_diagonal (N, T, U, 2)");
+    TORCH_CHECK(V >= 1 && V < (1ll << 31) && blank >= 0 && blank < V, "rnnt_loss status 5 "
+                "(RNNT_STATUS_INVALID_ARGUMENT): blank=", blank, " is not a vocabulary index (V=", V, ")");
     const c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(grads_diagonal.device());
     const int64_t N = grads_diagonal.size(0), T = grads_diagonal.size(1), U = grads_diagonal.size(2);
     at::Tensor out = at::empty({N, T, U, V}, grads_diagonal.options());
