@@ -451,10 +451,11 @@ hipError_t launch_lattice(hipStream_t stream, const LatticeArgs& a, int N, int l
         // (lattice_pd.hip), followed by the log-domain kernel for the (utterance, direction) pairs whose inputs it
         // flagged -- normally none: those workgroups return at once.  Where it pays, measured on MI355X
         // (tools/lattice_probe.py, us per alpha+beta sweep, probability domain / log domain):
-        //   N=16: T=1500 U=64 76/95, U=300 125/168, U=512 161/210; T=3000 U=500 (N=8) 224/376; T=700 U=100 57/63;
-        //         T=900 U=64 53/62; but T=400 U=100 43/42, T=500 U=300 85/76 (the hand-over lag between the column
-        //         blocks and the extra launches are only recovered on long sweeps);
-        //   T=1500 U=300: N=32 144/171, N=40 178/178, N=48 195/184, N=64 288/211 (its column blocks want a CU each).
+        //   N=16: T=1500 U=64 65/93, U=300 114/158, U=512 141/211; T=3000 U=500 (N=8) 200/376; T=700 U=100 53/60;
+        //         but T=400 U=100 40/40, T=150 U=40 20/16 (the hand-over lag between the column blocks and the extra
+        //         launches are only recovered on long sweeps);
+        //   T=1500 U=300: N=32 166/161, N=64 254/201 (its column blocks want a CU each).
+        //   (profiles/r02_lattice_probe.txt)
         // U <= 512 because the log-domain kernel behind it must be able to redo a sweep.
         // RNNT_LATTICE=logdomain|pd overrides the choice (A/B runs, tests).
         static const char* force = getenv("RNNT_LATTICE");
