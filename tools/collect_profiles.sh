@@ -29,12 +29,12 @@ RNNT_PARITY_TABLE=$OUT/parity_errors.json RNNT_PARITY_BUILD="default (probabilit
 RNNT_LATTICE=logdomain RNNT_PARITY_TABLE=$OUT/parity_errors.json RNNT_PARITY_BUILD="log-domain lattice, hardware exp2/log2 lse (RNNT_LATTICE=logdomain)" python -m pytest tests/test_gpu_baseline_sizes.py -q > $OUT/parity_logdomain.log 2>&1
 WARP_RNNT_AMD_LIB=$R/warp_rnnt_amd/libwarp_rnnt_amd_precise.so RNNT_PARITY_TABLE=$OUT/parity_errors.json RNNT_PARITY_BUILD="log-domain lattice, libm expf/log1pf (-DRNNT_PRECISE_LIBM)" python -m pytest tests/test_gpu_baseline_sizes.py -q > $OUT/parity_precise.log 2>&1
 # lattice kernel alone, both arithmetic domains
-python tools/lattice_probe.py pd2: > /dev/null 2>&1
-for sh in 16,1500,300 16,1500,64 16,1500,512 8,3000,500 32,1500,300 64,1500,300 16,700,100 16,400,100 16,150,40; do
+for sh in 16,1500,300 16,1500,64 16,1500,128 16,1500,512 8,3000,500 32,1500,300 64,1500,300 16,700,100 16,400,100 16,150,40; do
   for v in pd logdomain; do
-    RNNT_LATTICE=$v python tools/lattice_probe.py --shape $sh pd2: 2>&1 | grep median | sed "s/^pd2 */N,T,U=$sh lattice=$v  /"
+    RNNT_LATTICE=$v python tools/lattice_probe.py --shape $sh main: 2>&1 | grep median | sed "s/^main */N,T,U=$sh lattice=$v  /"
   done
 done > $OUT/lattice_probe.txt
+(python tools/graph_probe.py 16 150 40 28 0 1000; python tools/graph_probe.py 16 1500 300 50 1) 2>&1 | grep "N=" > $OUT/graph_probe.txt
 tools/ubench/pd_steps > $OUT/ubench_pd_steps.txt 2>&1
 python tools/host_overhead.py 2>&1 | grep -v amdgpu > $OUT/host_overhead.txt
 (echo "== ctypes fallback"; WARP_RNNT_AMD_NO_NATIVE_BINDING=1 python tools/host_overhead.py 2>&1 | grep -v amdgpu) >> $OUT/host_overhead.txt

@@ -49,7 +49,7 @@ def main():
     for f in glob.glob(os.path.join(SRC, "table_*.md")):
         shutil.copy(f, os.path.join(DST, f"{TAG}_" + os.path.basename(f)))
     for name in ("parity_errors.json", "lattice_probe.txt", "ubench_pd_steps.txt", "host_overhead.txt",
-                 "bench_c4_logdomain_lattice.json"):
+                 "bench_c4_logdomain_lattice.json", "graph_probe.txt"):
         if os.path.exists(os.path.join(SRC, name)):
             shutil.copy(os.path.join(SRC, name), os.path.join(DST, f"{TAG}_" + name))
     # HBM traffic of the dominant kernel, per launch (FETCH_SIZE doubled for wide coalesced reads)
