@@ -391,7 +391,10 @@ static hipError_t dispatch_lsm(hipStream_t stream, const float* x, float* out, c
         // and for the fused backward (+15 us).
         const bool wp = (L <= 16) && !no_wp && MODE == LSM_NORM;
         if (wp) R = rpp;
-        const size_t lds = (size_t)R * V * sizeof(float) + (GATHER ? (size_t)R * sizeof(float2) : 0);
+        size_t lds = (size_t)R * V * sizeof(float) + (GATHER ? (size_t)R * sizeof(float2) : 0);
+#ifdef RNNT_LG_PROBE      // probe: fewer resident workgroups per CU (LDS the kernel does not use)
+        if (const char* e = getenv("RNNT_LSM_LDS")) { const size_t want = (size_t)atoi(e); if (want > lds && want <= 65536) lds = want; }
+#endif
         const unsigned grid = (unsigned)((rows + R - 1) / R);
 #define LSM_SMALL(LL)                                                                           \
     case LL:                                                                                    \
