@@ -278,3 +278,30 @@ sys.stdout.buffer.write(c.detach().cpu().numpy().tobytes() + lp.grad.cpu().numpy
             assert r.returncode == 0, r.stderr.decode()[-2000:]
             outs.append(r.stdout)
         assert len(outs[0]) > 1000 and outs[0] == outs[1]
+
+
+# ---------------------------------------------------------------------------
+# the reference's benchmark CLI (tools/benchmark_table.py; pytorch_binding/benchmark.py:53-103): every --loss runs
+# on a small grid, prints the reference's line format and writes the table
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("loss", ["warp-rnnt", "warp-rnnt-gather", "warp-rnnt-compact", "warp-rnnt-fused",
+                                  "torch-log-softmax-gather"])
+def test_benchmark_table_cli(loss, tmp_path):
+    import re
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    md = tmp_path / "table.md"
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "benchmark_table.py"), "--loss", loss,
+                          "--grid", "2,30,9,11;2,150,40,28", "--batches", "1,3", "--random_length", "--markdown", str(md)],
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    text = out.stdout.decode()
+    assert out.returncode == 0, text[-2000:] + out.stderr.decode()[-2000:]
+    lines = re.findall(r"^T=(\d+)\tU=(\d+)\tV=(\d+)\tN=(\d+)\ttime=([0-9.]+)$", text, flags=re.M)
+    assert [(int(t), int(u), int(v), int(n)) for t, u, v, n, _ in lines] == \
+        [(30, 9, 11, 1), (30, 9, 11, 3), (150, 40, 28, 1), (150, 40, 28, 3)], text[-2000:]
+    assert all(0.0 < float(ms) < 1000.0 for *_, ms in lines)
+    table = md.read_text().splitlines()
+    assert len(table) == 2 + 4 and table[0].startswith("| T | U | V | N |")
+    # the reference's published cell is quoted where there is one (README.md:38: T=150,U=40,V=28,N=1)
+    assert table[4].split("|")[6].strip() in ("0.5", "0.54")
