@@ -153,6 +153,12 @@ for red in ("sum", "mean"):
     np.testing.assert_allclose(t.item(), want, rtol=1e-6)
 _, allc = reduce_costs(costs, "none")
 np.testing.assert_array_equal(allc.numpy(), full["costs"])
+_, allc = reduce_costs(costs, "none", n_global=5)                       # sizes known: one all-gather, no read-back
+np.testing.assert_array_equal(allc.numpy(), full["costs"])
+try:
+    reduce_costs(costs, "none", n_global=7); raise SystemExit("a wrong n_global must be rejected")
+except ValueError:
+    pass
 dist.barrier(); dist.destroy_process_group()
 print("rank", rank, "ok")
 '''

@@ -31,7 +31,7 @@ def shard_batch(tensors, rank: Optional[int] = None, world: Optional[int] = None
     return tuple(t[lo:hi].contiguous() for t in tensors)
 
 
-def reduce_costs(costs: torch.Tensor, reduction: str = "mean", group=None):
+def reduce_costs(costs: torch.Tensor, reduction: str = "mean", group=None, n_global: Optional[int] = None):
     """Global reduction of per-utterance costs computed on this rank's shard.
 
     Returns (loss, global_value):
@@ -42,7 +42,10 @@ def reduce_costs(costs: torch.Tensor, reduction: str = "mean", group=None):
                     gradient of the global loss.  No collective runs in backward.
       global_value  detached scalar, identical on every rank: the reduced loss over the whole
                     minibatch (for logging / early stopping).
-    For reduction='none' returns (local costs, all-gathered costs of the global batch in rank order).
+    For reduction='none' returns (local costs, all-gathered costs of the global batch in rank order).  When the
+    batch was sliced with :func:`shard_bounds` / :func:`shard_batch`, pass its size as ``n_global``: every rank then
+    knows every shard's size, and the exchange is ONE all-gather with no host synchronisation (without it the sizes
+    are gathered first and read back on the host).
     """
     if reduction not in ("mean", "sum", "none", None):
         raise ValueError(f"Unknown reduction method: {reduction}, expected to be one of ['mean', 'sum', 'none']")
@@ -50,10 +53,17 @@ def reduce_costs(costs: torch.Tensor, reduction: str = "mean", group=None):
     if reduction in ("none", None):
         if world == 1:
             return costs, costs.detach()
-        n = torch.tensor([costs.shape[0]], device=costs.device, dtype=torch.int64)
-        sizes = [torch.zeros_like(n) for _ in range(world)]
-        dist.all_gather(sizes, n, group=group)
-        sizes = [int(s.item()) for s in sizes]
+        if n_global is not None:
+            spans = [shard_bounds(n_global, r, world) for r in range(world)]
+            sizes = [hi - lo for lo, hi in spans]
+            if sizes[dist.get_rank(group)] != costs.shape[0]:
+                raise ValueError(f"rank {dist.get_rank(group)} holds {costs.shape[0]} costs, shard_bounds({n_global}, ...)"
+                                 f" gives it {sizes[dist.get_rank(group)]}")
+        else:
+            n = torch.tensor([costs.shape[0]], device=costs.device, dtype=torch.int64)
+            sizes = [torch.zeros_like(n) for _ in range(world)]
+            dist.all_gather(sizes, n, group=group)
+            sizes = [int(s.item()) for s in sizes]
         mx = max(sizes)
         pad = torch.zeros((mx,), dtype=costs.dtype, device=costs.device)
         pad[:costs.shape[0]] = costs.detach()
@@ -72,7 +82,7 @@ def reduce_costs(costs: torch.Tensor, reduction: str = "mean", group=None):
 
 
 def sharded_rnnt_loss(log_probs, labels, frames_lengths, labels_lengths, average_frames=False,
-                      reduction="mean", blank=0, gather=False, fastemit_lambda=0.0, group=None):
+                      reduction="mean", blank=0, gather=False, fastemit_lambda=0.0, group=None, n_global=None):
     """`warp_rnnt.rnnt_loss` on this rank's shard + the global scalar reduction.
 
     Arguments are this rank's slice of the minibatch (see :func:`shard_batch`).  Returns
@@ -82,4 +92,4 @@ def sharded_rnnt_loss(log_probs, labels, frames_lengths, labels_lengths, average
     costs = warp_rnnt.rnnt_loss(log_probs, labels, frames_lengths, labels_lengths,
                                 average_frames=average_frames, reduction="none", blank=blank,
                                 gather=gather, fastemit_lambda=fastemit_lambda)
-    return reduce_costs(costs, reduction, group)
+    return reduce_costs(costs, reduction, group, n_global)
