@@ -233,8 +233,9 @@ k_lsm_small(const float* x, float* out, const int* __restrict__ labels,
 // HBM write per element.
 // ---------------------------------------------------------------------------
 // Shape of the row-per-workgroup kernel: THREADS x NV float4 must cover a row.  The registers that hold
-// the row set the residency (NV=16 x 256 threads: 84 VGPRs, 5 waves/SIMD; NV=8: 8 waves/SIMD), so the
-// launcher picks the smallest cover: V <= 4096: 256x4, V <= 8192: 256x8, V <= 16384: 512x8.
+// the row set the residency (NV=16 x 256 threads: 84 VGPRs, 5 waves/SIMD; NV=8: 8 waves/SIMD).  The launcher
+// picks 1.25-2.5 float4 per thread for the plain log-softmax and the smallest cover for the read-mostly fused modes
+// (dispatch_lsm).
 constexpr int LG_MAXV = 16384;
 
 template <int THREADS>
@@ -421,12 +422,28 @@ static hipError_t dispatch_lsm(hipStream_t stream, const float* x, float* out, c
 #undef LGV
         }
 #endif
-        if (V <= 4096)
-            k_lsm_large<MODE, 256, 4><<<grid, 256, 0, stream>>>(x, out, labels, rows, V, T, U, blank, bw);
-        else if (V <= 8192)
-            k_lsm_large<MODE, 256, 8><<<grid, 256, 0, stream>>>(x, out, labels, rows, V, T, U, blank, bw);
-        else
-            k_lsm_large<MODE, 512, 8><<<grid, 512, 0, stream>>>(x, out, labels, rows, V, T, U, blank, bw);
+        if constexpr (MODE == LSM_NORM) {
+            // The read + write stream wants 1.25-2.5 float4 per thread, whatever that does to the residency
+            // (profiles/r02_lsm_large_variants.txt, threads x float4, us for ~1.9 GB in + out: V=3000 256x4 734 /
+            // 512x4 648; V=5000 256x8 710 / 512x4 689; V=8192 256x8 687 / 1024x2 666; V=10000 512x8 870 / 1024x4 828;
+            // V=16384 512x8 707 / 1024x4 723).
+            if (V <= 2560)
+                k_lsm_large<MODE, 256, 4><<<grid, 256, 0, stream>>>(x, out, labels, rows, V, T, U, blank, bw);
+            else if (V <= 5120)
+                k_lsm_large<MODE, 512, 4><<<grid, 512, 0, stream>>>(x, out, labels, rows, V, T, U, blank, bw);
+            else if (V <= 12288)
+                k_lsm_large<MODE, 1024, 4><<<grid, 1024, 0, stream>>>(x, out, labels, rows, V, T, U, blank, bw);
+            else
+                k_lsm_large<MODE, 512, 8><<<grid, 512, 0, stream>>>(x, out, labels, rows, V, T, U, blank, bw);
+        } else {
+            // read-mostly modes (fused gather, fused backward): the smallest cover, for the residency
+            if (V <= 4096)
+                k_lsm_large<MODE, 256, 4><<<grid, 256, 0, stream>>>(x, out, labels, rows, V, T, U, blank, bw);
+            else if (V <= 8192)
+                k_lsm_large<MODE, 256, 8><<<grid, 256, 0, stream>>>(x, out, labels, rows, V, T, U, blank, bw);
+            else
+                k_lsm_large<MODE, 512, 8><<<grid, 512, 0, stream>>>(x, out, labels, rows, V, T, U, blank, bw);
+        }
     } else {
         k_lsm_generic<MODE><<<(unsigned)((rows + 3) / 4), 256, 0, stream>>>(x, out, labels, rows, V, T,
                                                                              U, blank, bw);
@@ -561,9 +578,17 @@ hipError_t launch_log_softmax_backward(hipStream_t stream, const float* dy, cons
 #undef LSMB_SMALL
     } else if (aligned && V % 4 == 0 && V <= LG_MAXV) {
         const unsigned grid = (unsigned)(rows < (1 << 22) ? rows : (1 << 22));
-        if (V <= 4096) k_lsmbwd_large<256, 4><<<grid, 256, 0, stream>>>(dy, y, dx, rows, V);
-        else if (V <= 8192) k_lsmbwd_large<256, 8><<<grid, 256, 0, stream>>>(dy, y, dx, rows, V);
-        else k_lsmbwd_large<512, 8><<<grid, 512, 0, stream>>>(dy, y, dx, rows, V);
+        static const bool old_rule = getenv("RNNT_LSMBWD_SMALLEST_COVER") != nullptr;    // (A/B knob)
+        if (old_rule) {
+            if (V <= 4096) k_lsmbwd_large<256, 4><<<grid, 256, 0, stream>>>(dy, y, dx, rows, V);
+            else if (V <= 8192) k_lsmbwd_large<256, 8><<<grid, 256, 0, stream>>>(dy, y, dx, rows, V);
+            else k_lsmbwd_large<512, 8><<<grid, 512, 0, stream>>>(dy, y, dx, rows, V);
+        } else {      // as the forward kernel (dispatch_lsm): 1.25-2.5 float4 per thread
+            if (V <= 2560) k_lsmbwd_large<256, 4><<<grid, 256, 0, stream>>>(dy, y, dx, rows, V);
+            else if (V <= 5120) k_lsmbwd_large<512, 4><<<grid, 512, 0, stream>>>(dy, y, dx, rows, V);
+            else if (V <= 12288) k_lsmbwd_large<1024, 4><<<grid, 1024, 0, stream>>>(dy, y, dx, rows, V);
+            else k_lsmbwd_large<512, 8><<<grid, 512, 0, stream>>>(dy, y, dx, rows, V);
+        }
     } else {
         k_lsmbwd_generic<<<(unsigned)((rows + 3) / 4), 256, 0, stream>>>(dy, y, dx, rows, V);
     }
