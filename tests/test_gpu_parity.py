@@ -180,7 +180,9 @@ def test_calls_stress():
 # ----------------------------------------------------------------------------
 # 4. prologue kernels
 # ----------------------------------------------------------------------------
-@pytest.mark.parametrize("V", [2, 3, 5, 28, 50, 51, 64, 257, 600, 1024, 1028, 1030, 5000, 10000, 20000])
+# (1024 / 2560 / 5120 / 12288 / 16384: where the launcher changes kernel or workgroup shape, prologue.hip: dispatch_lsm)
+@pytest.mark.parametrize("V", [2, 3, 5, 28, 50, 51, 64, 257, 600, 1024, 1028, 1030, 2560, 2564, 5000, 5120, 5124,
+                               10000, 12288, 12292, 16384, 16388, 20000])
 def test_log_softmax_kernel(V):
     from warp_rnnt_amd import ops
     rows = 1000 if V < 2000 else 77

@@ -174,7 +174,8 @@ def test_hip_graph_capture_and_replay():
     np.testing.assert_allclose(g.cpu().numpy(), ref["grads"], atol=1e-4)
 
 
-@pytest.mark.parametrize("shape", [(1000, 50), (37, 5000), (64, 1030), (5, 7, 3, 28), (11, 2)])
+@pytest.mark.parametrize("shape", [(1000, 50), (37, 5000), (64, 1030), (5, 7, 3, 28), (11, 2), (33, 2560), (33, 2564),
+                                   (21, 5124), (9, 10000), (9, 12292), (5, 16384), (3, 17000)])
 def test_log_softmax_autograd(shape):
     from warp_rnnt_amd.functional import log_softmax
     x = (torch.randn(*shape, device=DEV) * 2).requires_grad_(True)
