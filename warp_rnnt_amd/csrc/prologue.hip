@@ -423,18 +423,25 @@ static hipError_t dispatch_lsm(hipStream_t stream, const float* x, float* out, c
         }
 #endif
         if constexpr (MODE == LSM_NORM) {
-            // The read + write stream wants 1.25-2.5 float4 per thread, whatever that does to the residency
-            // (profiles/r02_lsm_large_variants.txt, threads x float4, us for ~1.9 GB in + out: V=3000 256x4 734 /
-            // 512x4 648; V=5000 256x8 710 / 512x4 689; V=8192 256x8 687 / 1024x2 666; V=10000 512x8 870 / 1024x4 828;
-            // V=16384 512x8 707 / 1024x4 723).
-            if (V <= 2560)
-                k_lsm_large<MODE, 256, 4><<<grid, 256, 0, stream>>>(x, out, labels, rows, V, T, U, blank, bw);
-            else if (V <= 5120)
-                k_lsm_large<MODE, 512, 4><<<grid, 512, 0, stream>>>(x, out, labels, rows, V, T, U, blank, bw);
-            else if (V <= 12288)
-                k_lsm_large<MODE, 1024, 4><<<grid, 1024, 0, stream>>>(x, out, labels, rows, V, T, U, blank, bw);
-            else
+            // The read + write stream wants about two float4 per thread and (nearly) every thread busy in every pass,
+            // whatever that does to the residency (profiles/r02_lsm_large_variants.txt, threads x passes, us for
+            // ~1.9 GB in + out: V=3000 256x3 734 / 384x2 663; V=5000 256x5 710 / 512x3 689-705 / 640x2 662-673;
+            // V=8192 256x8 687 / 1024x2 666; V=10000 512x5 870 / 1024x3 828-834 / 896x3 811; V=16384 512x8 707 /
+            // 1024x4 723).  Thread counts in steps of two waves; the count is a template parameter on purpose (the
+            // same kernel with blockDim.x read at run time: 780 us at V=5000).
+            const int nvec = V >> 2;
+            const int passes = nvec <= 2048 ? 2 : 3;
+            int th = (nvec + 128 * passes - 1) / (128 * passes) * 128;
+            th = th < 256 ? 256 : th;
+#define LGN(TH, NV) case TH: k_lsm_large<MODE, TH, NV><<<grid, TH, 0, stream>>>(x, out, labels, rows, V, T, U, blank, bw); break;
+            if (nvec > 3072) {
                 k_lsm_large<MODE, 512, 8><<<grid, 512, 0, stream>>>(x, out, labels, rows, V, T, U, blank, bw);
+            } else if (passes == 2) {
+                switch (th) { LGN(256, 2) LGN(384, 2) LGN(512, 2) LGN(640, 2) LGN(768, 2) LGN(896, 2) LGN(1024, 2) }
+            } else {
+                switch (th) { LGN(768, 3) LGN(896, 3) LGN(1024, 3) }
+            }
+#undef LGN
         } else {
             // read-mostly modes (fused gather, fused backward): the smallest cover, for the residency
             if (V <= 4096)
@@ -583,11 +590,20 @@ hipError_t launch_log_softmax_backward(hipStream_t stream, const float* dy, cons
             if (V <= 4096) k_lsmbwd_large<256, 4><<<grid, 256, 0, stream>>>(dy, y, dx, rows, V);
             else if (V <= 8192) k_lsmbwd_large<256, 8><<<grid, 256, 0, stream>>>(dy, y, dx, rows, V);
             else k_lsmbwd_large<512, 8><<<grid, 512, 0, stream>>>(dy, y, dx, rows, V);
-        } else {      // as the forward kernel (dispatch_lsm): 1.25-2.5 float4 per thread
-            if (V <= 2560) k_lsmbwd_large<256, 4><<<grid, 256, 0, stream>>>(dy, y, dx, rows, V);
-            else if (V <= 5120) k_lsmbwd_large<512, 4><<<grid, 512, 0, stream>>>(dy, y, dx, rows, V);
-            else if (V <= 12288) k_lsmbwd_large<1024, 4><<<grid, 1024, 0, stream>>>(dy, y, dx, rows, V);
-            else k_lsmbwd_large<512, 8><<<grid, 512, 0, stream>>>(dy, y, dx, rows, V);
+        } else {      // as the forward kernel (dispatch_lsm): two or three passes, (nearly) every thread busy
+            const int nvec = V >> 2;
+            const int passes = nvec <= 2048 ? 2 : 3;
+            int th = (nvec + 128 * passes - 1) / (128 * passes) * 128;
+            th = th < 256 ? 256 : th;
+#define LGB(TH, NV) case TH: k_lsmbwd_large<TH, NV><<<grid, TH, 0, stream>>>(dy, y, dx, rows, V); break;
+            if (nvec > 3072) {
+                k_lsmbwd_large<512, 8><<<grid, 512, 0, stream>>>(dy, y, dx, rows, V);
+            } else if (passes == 2) {
+                switch (th) { LGB(256, 2) LGB(384, 2) LGB(512, 2) LGB(640, 2) LGB(768, 2) LGB(896, 2) LGB(1024, 2) }
+            } else {
+                switch (th) { LGB(768, 3) LGB(896, 3) LGB(1024, 3) }
+            }
+#undef LGB
         }
     } else {
         k_lsmbwd_generic<<<(unsigned)((rows + 3) / 4), 256, 0, stream>>>(dy, y, dx, rows, V);
