@@ -2,8 +2,16 @@
  * warp_rnnt_amd.h -- C ABI of the MI355X-native RNN-Transducer loss
  * (libwarp_rnnt_amd.so).  Plain pointers and sizes only; every pointer is a
  * DEVICE pointer unless stated otherwise; every call only ENQUEUES work on
- * `stream` (no allocation, no host synchronisation, no global state), so the
- * library is re-entrant across streams and threads.
+ * `stream` (no allocation, no host synchronisation), so the library is
+ * re-entrant across streams and threads.  State the library keeps, all of it
+ * harmless to share: the lattice route (rnnt_amd_set_lattice: one atomic int,
+ * read once per call), a launch counter per process and one per device (they
+ * only make the hand-over tags of the probability-domain lattice kernel unique
+ * per launch and per graph replay), a few A/B knobs read once from the
+ * environment (RNNT_LSM_NO_WP, RNNT_LSMBWD_SMALLEST_COVER), a per-thread status
+ * for the void-returning compact entry points (rnnt_amd_compact_last_status)
+ * and a once-per-process kernel attribute.  Nothing depends on what an earlier
+ * call left in a workspace: scratch contents are unspecified on entry and exit.
  *
  * Part 1 mirrors the reference's own C interface (1ytic/warp-rnnt core.h: all
  * five entry points, padded and compact) so that the reference's bindings can
@@ -215,6 +223,23 @@ rnntStatus_t rnnt_amd_debug_lattice_only(rnntStream_t stream, void *workspace, c
  * sweep `dir` (0 alpha, 1 beta) of utterance n was redone in the log domain (bit 0: an input outside the range
  * the probability domain carries; bit 1: a hand-over between column blocks timed out). */
 size_t rnnt_amd_debug_redo_offset(int N, int T, int U);
+
+/*
+ * Which arithmetic sweeps the lattice of the workspace-based calls (rnnt_amd_loss, rnnt_amd_loss_compact):
+ *   0 auto       probability domain (fp64 mantissa + per-column exponent) where it is the faster
+ *                kernel -- long lattices: T >= 640, T >= 2U, U <= 512, padded layout, 2N*ceil(U/64) <= 256 --
+ *                and the log domain elsewhere;
+ *   1 logdomain  always the reference's arithmetic (fp32 log-sum-exp per cell, core_gather.cu:22-35,106-126);
+ *   2 pd         probability domain wherever it is supported (padded layout, U <= 512), log domain elsewhere.
+ * Both agree with each other and with the reference to fp32 rounding on short lattices; on long ones the log
+ * domain accumulates ~ulp(|alpha|) per step (1e-2 on the gradients at T=1500, U=300) and the probability domain
+ * does not (7e-4), so results depend on the route -- and, on `auto`, on the batch shape.  Pin it for bit-stable
+ * results across batch shapes.  Process-wide, read once per call, may be changed at any time; the initial value
+ * comes from the environment variable RNNT_LATTICE (logdomain | pd).  The reference-named entry points of Part 1
+ * always run the log domain on the caller's layout.  Returns the previous setting, or -1 for an unknown value.
+ */
+int rnnt_amd_set_lattice(int route);
+int rnnt_amd_get_lattice(void);
 
 /* Library version, for the host-side loader. */
 int rnnt_amd_version(void);

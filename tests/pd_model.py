@@ -17,7 +17,12 @@ Scheme (alpha; beta is the mirrored lattice):
                        that have not started yet adopt the exponent of the last started column, and the
                        factors 2**(E[u-1]-E[u]) are rebuilt.
     fp64 keeps 2**+-1022: K steps of the smallest fp32-representable probability (2**-126) cannot leave it,
-    so there is no range bookkeeping besides "every finite log-prob is above -80" (else: log-domain kernel).
+    so the only bookkeeping inside an interval is none.  What is checked, off the chain: every finite log-prob is
+    above -80; the exponent gap between neighbouring live columns at a renormalisation stays within MAX_GAP (a
+    frame at which the label probabilities step up puts (pL(t+1)/pL(t))**u between two columns of one diagonal --
+    2**1558 with every log-prob above -10 -- and the factor 2**gap must stay an fp64); and every column's final
+    value is a positive finite number (an overflow, a NaN or a total underflow anywhere upstream is sticky).
+    A sweep that fails any of them is redone by the log-domain kernel.
     stored alpha       = ln2 * (log2(m) + e) with m = the top 24 significant bits of val as an fp32 in [1,2),
                          e = its binary exponent + E   (v_log_f32, one multiply, one fma: <= 0.5 ulp of the result)
 """
@@ -25,6 +30,8 @@ import numpy as np
 
 K = 8                  # diagonals between renormalisations (= one block of the kernel)
 LP_MIN = -80.0         # log-probs below this (p would flush to 0 in fp32) send the utterance to the log-domain kernel
+MAX_GAP = 400          # largest |E[u-1] - E[u]| between live columns the fp64 state is trusted with (lattice_pd.hip)
+GAP_CLAMP = 1000       # the shift is clamped so that the factor stays finite whatever the gap
 LOG2E = np.float32(1.44269504088896340736)
 LN2 = np.float32(0.693147180559945309417)
 
@@ -55,7 +62,9 @@ def out_log(val, E):
 
 def sweep(lpB, lpL, beta=False, k_renorm=K):
     """One direction of one utterance.  lpB, lpL: (T,U) log-probs (lpL[:, U-1] unused).
-    Returns (log-values (T,U) fp32, log-likelihood fp32 [alpha only, else None])."""
+    Returns (log-values (T,U) fp32, log-likelihood fp32 [alpha only, else None], chain_ok): chain_ok is False when
+    the kernel would flag the sweep for the log-domain kernel (column gap beyond MAX_GAP, non-finite or zero final
+    value)."""
     T, U = lpB.shape
     if beta:
         # mirrored lattice: sweep cell (t',u') is lattice cell (T-1-t', U-1-u'); both weights of the beta
@@ -70,6 +79,7 @@ def sweep(lpB, lpL, beta=False, k_renorm=K):
     Y[0] = 1.0
     c = np.ones(U)
     ucol = np.arange(U)
+    gap_hi = gap_lo = 0
     for d in range(T + U - 1):
         if d % k_renorm == 0:
             started = (ucol <= d - 1) | (ucol == 0)      # column 0 carries the initial 1 from the start
@@ -81,7 +91,11 @@ def sweep(lpB, lpL, beta=False, k_renorm=K):
             E = np.where(started, E, E[min(front, U - 1)])
             dE = np.zeros(U, np.int64)
             dE[1:] = E[:-1] - E[1:]
-            c = np.ldexp(np.ones(U), dE)
+            done = (d - ucol) >= T                       # a finished column's exponent is frozen: not a lattice gap
+            judged = np.where(done, 0, dE)
+            gap_hi, gap_lo = max(gap_hi, int(judged.max())), min(gap_lo, int(judged.min()))
+            with np.errstate(over="ignore", under="ignore"):
+                c = np.ldexp(np.ones(U), np.clip(dE, -GAP_CLAMP, GAP_CLAMP))
             c[0] = 0.0
         t = d - ucol
         live = (t >= 0) & (t < T)
@@ -89,22 +103,24 @@ def sweep(lpB, lpL, beta=False, k_renorm=K):
         b, l = pB[tc, ucol], pL[tc, ucol]
         Xl = np.zeros(U)
         Xl[1:] = X[:-1]
-        if beta:
-            val = Xl * (l * c) + Y * b                   # tmp = pL*c ; S = Y*pB ; val = fma(X_left, tmp, S)
-            Yn, Xn = val, val
-        else:
-            val = Xl * c + Y                             # fma
-            Xn = val * l
-            Yn = val * b
-        out[tc[live], ucol[live]] = out_log(val[live], E[live])
+        with np.errstate(over="ignore", invalid="ignore", under="ignore"):
+            if beta:
+                val = Xl * (l * c) + Y * b               # tmp = pL*c ; S = Y*pB ; val = fma(X_left, tmp, S)
+                Yn, Xn = val, val
+            else:
+                val = Xl * c + Y                         # fma
+                Xn = val * l
+                Yn = val * b
+            out[tc[live], ucol[live]] = out_log(np.nan_to_num(val[live], nan=0.0, posinf=0.0), E[live])
         Y = np.where(live, Yn, Y)
         X = np.where(live, Xn, X)
+    chain_ok = bool(gap_hi <= MAX_GAP and gap_lo >= -MAX_GAP and np.all((Y > 0) & np.isfinite(Y)))
     ll = None
     if not beta:
-        ll = out_log(Y[U - 1:U], E[U - 1:U])[0]
+        ll = out_log(np.nan_to_num(Y[U - 1:U], nan=0.0, posinf=0.0), E[U - 1:U])[0]
     else:
         out = out[::-1, ::-1]
-    return out, ll
+    return out, ll, chain_ok
 
 
 def in_range(lp2):
@@ -115,8 +131,10 @@ def in_range(lp2):
 
 
 def lattice(lp2, k_renorm=K):
-    """(T,U,2) gathered log-probs of one utterance -> alphas, betas (log, fp32), ll_alpha, in_range."""
+    """(T,U,2) gathered log-probs of one utterance -> alphas, betas (log, fp32), ll_alpha, ok.  ok = the kernel
+    keeps both sweeps (inputs in range and both chains in range); otherwise the log-domain kernel redoes what was
+    flagged and the values returned here are not what the caller sees."""
     lpB, lpL = lp2[..., 0], lp2[..., 1]
-    al, ll = sweep(lpB, lpL, beta=False, k_renorm=k_renorm)
-    be, _ = sweep(lpB, lpL, beta=True, k_renorm=k_renorm)
-    return al, be, ll, in_range(lp2)
+    al, ll, ok_a = sweep(lpB, lpL, beta=False, k_renorm=k_renorm)
+    be, _, ok_b = sweep(lpB, lpL, beta=True, k_renorm=k_renorm)
+    return al, be, ll, in_range(lp2) and ok_a and ok_b

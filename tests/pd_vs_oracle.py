@@ -1,5 +1,6 @@
-"""Runs in a subprocess of tests/test_gpu_pd.py with RNNT_LATTICE=pd: the probability-domain lattice kernel
-(csrc/lattice_pd.hip) forced on for every shape it supports, against the fp32 oracle -- including the shapes
+"""Runs in a subprocess of tests/test_gpu_pd.py (its own process because one of the two runs loads another build of
+the library): the probability-domain lattice kernel (csrc/lattice_pd.hip) forced on -- warp_rnnt_amd.set_lattice("pd")
+-- for every shape it supports, against the fp32 oracle -- including the shapes
 around its structural boundaries (column blocks of 64 = workgroups, blocks of 8 diagonals, late-starting and
 early-finishing lanes), inputs it must hand to the log-domain kernel, and repeated launches on one workspace
 (launch epochs of the hand-over rings)."""
@@ -58,8 +59,20 @@ def check(name, lp2, xn, yn, lam=0.0, grad_atol=None):
     np.testing.assert_allclose(g, ref["grads"], atol=grad_atol, err_msg=name)
 
 
+def step_case(N, T, U, t_step, lo, hi):
+    """Label log-probs `lo` up to frame t_step and `hi` after it (blank: the rest of the mass).  Every input is in
+    range, but two columns of a diagonal that crosses the step differ by exp((hi-lo)*u): beyond fp64."""
+    lp2 = np.zeros((N, T, U, 2), np.float32)
+    lab = np.where(np.arange(T) <= t_step, lo, hi).astype(np.float64)
+    lp2[..., 1] = lab[None, :, None]
+    lp2[..., 0] = np.log1p(-np.exp(lab))[None, :, None]
+    return lp2
+
+
 def main():
-    assert os.environ.get("RNNT_LATTICE") == "pd"
+    import warp_rnnt_amd
+    warp_rnnt_amd.set_lattice("pd")
+    assert warp_rnnt_amd.get_lattice() == "pd"
     rng = np.random.RandomState(5)
     shapes = [(3, t, u) for u in (2, 31, 63, 64, 65, 127, 128, 129, 200) for t in (1, 2, 7, 8, 9, 33)]
     shapes += [(2, 20, 511), (2, 20, 512), (2, 257, 300), (1, 40, 320), (4, 150, 40), (2, 300, 257), (2, 70, 1),
@@ -91,11 +104,32 @@ def main():
     lp2[1, 3, 4, 1] = -95.0
     lp2[2, 7, 2, 0] = -1000.0
     lp2[3, 9, 69, 1] = -3.0e4          # label channel of the last column: not part of the lattice, must not matter
-    os.environ.pop("RNNT_LATTICE")     # (read once by the library: this changes nothing for this process)
     ref = oracle.rnnt_loss_f32(lp2, None, xn, yn, blank=-1, scan_mode=1)
     c, g = native(lp2, xn, yn)
     np.testing.assert_allclose(c, ref["costs"], rtol=1e-5)
     np.testing.assert_allclose(g, ref["grads"], atol=1e-4)
+    # inputs inside the range whose COLUMNS drift further apart than an fp64 holds (a step in the label
+    # probabilities): the chain's own range check must flag the sweeps, the log-domain kernel redoes them
+    for (T, U, ts, lo, hi) in ((300, 120, 150, -10.0, -1.0), (60, 24, 30, -70.0, -1e-3), (700, 200, 350, -9.0, -0.5)):
+        lp2 = step_case(2, T, U, ts, lo, hi)
+        xn, yn = np.full((2,), T, np.int32), np.full((2,), U - 1, np.int32)
+        xn[1], yn[1] = T - 3, U - 2
+        ref = oracle.rnnt_loss_f32(lp2, None, xn, yn, blank=-1, scan_mode=1)
+        c, g = native(lp2, xn, yn)
+        # (every cell of a frame holds the same two numbers here, so the rounding of the two fp32 lse flavours --
+        #  hardware exp2/log2 on the GPU, libm in the oracle -- does not average out along the sweep: 2e-5 relative
+        #  on the cost at T+U = 900, where random inputs give 1e-6)
+        np.testing.assert_allclose(c, ref["costs"], rtol=1e-4, err_msg=f"step case {T}x{U}")
+        np.testing.assert_allclose(g, ref["grads"], atol=5e-4 * max(1.0, float(np.abs(ref["costs"]).max()) / 100.0),
+                                   err_msg=f"step case {T}x{U}")
+        flags = redo_flags(lp2, xn, yn)
+        assert (flags & 1).all(), (T, U, flags)          # both sweeps of both utterances cross the step
+        # ... so what came back is the log-domain kernel's result, bit for bit
+        warp_rnnt_amd.set_lattice("logdomain")
+        c_ld, g_ld = native(lp2, xn, yn)
+        warp_rnnt_amd.set_lattice("pd")
+        np.testing.assert_array_equal(c, c_ld, err_msg=f"step case {T}x{U}")
+        np.testing.assert_array_equal(g, g_ld, err_msg=f"step case {T}x{U}")
     lpg = np.full((3, 1, 4, 2), -1.0, dtype=np.float32)
     lpg[1, 0, :, 1] = [3e8, -7.0, -3e8, 0.0]
     lpg[1, 0, 3, 0] = -2.0

@@ -95,3 +95,58 @@ def test_training_step_replays():
         torch.cuda.synchronize()
         assert torch.equal(loss, want[k][0]), f"replay {rep}: loss {loss.item()} vs eager {want[k][0].item()}"
         assert torch.equal(x.grad, want[k][1]), f"replay {rep}: d/d logits differ from eager"
+
+
+def test_replays_do_not_depend_on_what_the_workspace_holds():
+    """The workspace is caller scratch with unspecified contents (include/warp_rnnt_amd.h).  Under capture it is a
+    tensor freed back to the graph's pool, so between replays anything may land in it: the previous replay's
+    hand-over granules (the realistic case), constant bytes, random bytes.  k_prepare clears the rings and takes the
+    launch epoch from the library's own device-side counter, so every replay must reproduce the eager result
+    (with the counter in the workspace, constant data over that word froze the epoch)."""
+    import torch
+    import warp_rnnt_amd
+    from warp_rnnt_amd import _lib, ops
+    L = _lib.load()
+    N, T, U, V = 2, 700, 150, 11                       # three column blocks per sweep: two hand-over rings each
+    dev = torch.device("cuda:0")
+    sets = [tuple(t.to(dev) for t in _inputs(torch, N, T, U, V, seed)) for seed in (11, 12, 13)]
+    ws = torch.empty((L.rnnt_amd_workspace_size(N, T, U),), dtype=torch.uint8, device=dev)
+    costs = torch.empty((N,), device=dev)
+    grads = torch.empty((N, T, U, 2), device=dev)
+    static = [t.clone() for t in sets[0]]
+
+    def call():
+        st = L.rnnt_amd_loss(torch.cuda.current_stream().cuda_stream, ws.data_ptr(), ops.IN_LOG_PROBS_DENSE,
+                             static[0].data_ptr(), static[1].data_ptr(), static[2].data_ptr(), static[3].data_ptr(),
+                             costs.data_ptr(), grads.data_ptr(), ops.GRADS_GATHERED, N, T, U, V, 0, 0.0)
+        assert st == 0
+
+    with warp_rnnt_amd.lattice_route("pd"):
+        eager = []
+        for s in sets:
+            for dst, src in zip(static, s):
+                dst.copy_(src)
+            ws.random_(0, 256)
+            call()
+            torch.cuda.synchronize()
+            eager.append((costs.clone(), grads.clone()))
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            call()
+        torch.cuda.current_stream().wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            call()
+    for rep in range(15):
+        k = rep % len(sets)
+        for dst, src in zip(static, sets[k]):
+            dst.copy_(src)
+        if rep % 3 == 1:
+            ws.fill_(0x5A)
+        elif rep % 3 == 2:
+            ws.random_(0, 256)
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(costs, eager[k][0]), f"replay {rep}: costs {costs.tolist()} vs eager {eager[k][0].tolist()}"
+        assert torch.equal(grads, eager[k][1]), f"replay {rep}: gradients differ from eager"

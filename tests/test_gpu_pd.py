@@ -1,6 +1,6 @@
 """The probability-domain lattice kernel is chosen automatically only for long lattices of small batches
-(csrc/lattice.hip: launch_lattice); here it is forced on for everything it supports (RNNT_LATTICE=pd is read
-once per process, hence the subprocess) and compared with the fp32 oracle.  The default routing is what the
+(csrc/lattice.hip: launch_lattice); here it is forced on for everything it supports (warp_rnnt_amd.set_lattice("pd");
+a subprocess because the second test loads another build of the library) and compared with the fp32 oracle.  The default routing is what the
 other GPU tests exercise: short lattices run the log-domain kernels, c4 and c5 of
 tests/test_gpu_baseline_sizes.py the probability-domain one."""
 import os
@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 
 
 def test_forced_probability_domain_kernel_against_oracle():
-    env = dict(os.environ, RNNT_LATTICE="pd")
+    env = dict(os.environ)
     out = subprocess.run([sys.executable, os.path.join(HERE, "pd_vs_oracle.py")], env=env, stdout=subprocess.PIPE,
                          stderr=subprocess.STDOUT, timeout=900)
     text = out.stdout.decode()
@@ -29,7 +29,7 @@ def test_lost_hand_over_falls_back_to_log_domain_kernel():
     lib = _build.variant_path("short_spin")
     if not os.path.exists(lib):
         _build.build(variant="short_spin")
-    env = dict(os.environ, RNNT_LATTICE="pd", WARP_RNNT_AMD_LIB=lib, PD_VS_ORACLE_EXPECT_REDO="1")
+    env = dict(os.environ, WARP_RNNT_AMD_LIB=lib, PD_VS_ORACLE_EXPECT_REDO="1")
     out = subprocess.run([sys.executable, os.path.join(HERE, "pd_vs_oracle.py")], env=env, stdout=subprocess.PIPE,
                          stderr=subprocess.STDOUT, timeout=900)
     text = out.stdout.decode()

@@ -255,3 +255,66 @@ def test_compiled_binding_is_built_and_checks_arguments_like_the_reference():
     # keyword names of the reference's module (binding.cpp:250-254; used as kwargs at __init__.py:13-18)
     with pytest.raises(RuntimeError, match="located in the CUDA"):
         nat.rnnt_loss(xs=xs, ys=e, xn=e, yn=e, blank=0, fastemit_lambda=0.0)
+
+
+REFERENCE_BINDING = "/root/reference/pytorch_binding/binding.cpp"
+
+# what a maintainer of the reference changes in pytorch_binding/binding.cpp.  The first
+# edit is the header; the rest is what PyTorch-ROCm's own hipify pass does to every extension source (CUDA c10
+# names -> their "masquerading" HIP twins), written out so that the test does not depend on that tool.
+REFERENCE_BINDING_EDITS = [
+    ('#include "core.h"', '#include "warp_rnnt_amd.h"'),
+    ("#include <c10/cuda/CUDAGuard.h>", "#include <ATen/hip/impl/HIPGuardImplMasqueradingAsCUDA.h>"),
+    ("#include <c10/cuda/CUDAStream.h>", "#include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>"),
+    ("c10::cuda::getCurrentCUDAStream(", "c10::hip::getCurrentHIPStreamMasqueradingAsCUDA("),
+    ("at::cuda::OptionalCUDAGuard", "c10::hip::OptionalHIPGuardMasqueradingAsCUDA"),
+]
+
+
+@pytest.mark.skipif(not os.path.exists(REFERENCE_BINDING), reason="reference checkout not present (GPU box)")
+def test_reference_binding_links_against_this_library(tmp_path):
+    """INTEGRATION.md section 1 says the reference's own pytorch_binding/binding.cpp links whole against
+    include/warp_rnnt_amd.h + libwarp_rnnt_amd.so (binding.cpp:85-99 run_warp_rnnt[_gather], :170,:197,:241 the
+    three compact entry points).  Build container only: the file is read where it lies, edited in memory, compiled
+    in a temporary directory with every symbol required to resolve (-Wl,--no-undefined), imported, and thrown away."""
+    import importlib.util
+    import shutil
+    import sysconfig
+    from torch.utils import cpp_extension as ce
+    from warp_rnnt_amd import _build
+    gxx = shutil.which(os.environ.get("CXX", "g++"))
+    if gxx is None:
+        pytest.skip("no g++")
+    lib = _build.build()
+    text = open(REFERENCE_BINDING).read()
+    for old, new in REFERENCE_BINDING_EDITS:
+        assert old in text, f"the reference's binding.cpp no longer contains {old!r}"
+        text = text.replace(old, new)
+    for name in ("run_warp_rnnt(", "run_warp_rnnt_gather(", "run_gather_for_compact(", "run_warp_rnnt_compact(",
+                 "run_scatter_grad_for_compact("):
+        assert name in text                      # the five core.h entry points are what it calls
+    src = tmp_path / "binding_ref_edited.cpp"
+    src.write_text(text)
+    out = tmp_path / "_C_ref.so"
+    tdir = os.path.dirname(torch.__file__)
+    cmd = [gxx, "-O1", "-std=c++17", "-fPIC", "-shared", "-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1",
+           "-DTORCH_EXTENSION_NAME=_C_ref", "-DTORCH_API_INCLUDE_EXTENSION_H",
+           "-D_GLIBCXX_USE_CXX11_ABI=%d" % int(torch._C._GLIBCXX_USE_CXX11_ABI),
+           "-I" + os.path.join(ROOT, "include")]
+    cmd += ["-I" + p for p in ce.include_paths(device_type="cuda")] + ["-I" + sysconfig.get_paths()["include"]]
+    cmd += [str(src), "-o", str(out), "-Wl,--no-undefined", "-L" + os.path.join(tdir, "lib"),
+            "-L" + os.path.dirname(lib), "-lwarp_rnnt_amd", "-lc10", "-lc10_hip", "-ltorch_cpu", "-ltorch_hip",
+            "-ltorch", "-ltorch_python", "-lamdhip64",
+            "-L" + sysconfig.get_config_var("LIBDIR"), "-lpython" + sysconfig.get_config_var("LDVERSION"),
+            "-Wl,-rpath," + os.path.dirname(lib), "-Wl,-rpath," + os.path.join(tdir, "lib")]
+    res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+    assert res.returncode == 0, res.stdout.decode()[-6000:]
+    # the module imports and carries the reference's three ops; its argument checks run before any device work
+    spec = importlib.util.spec_from_file_location("_C_ref", str(out))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    for fn in ("rnnt_loss", "rnnt_loss_compact", "rnnt_loss_compact_backward"):      # binding.cpp:250-266
+        assert hasattr(mod, fn), dir(mod)
+    e = torch.tensor([], dtype=torch.int)
+    with pytest.raises(RuntimeError, match="xs must be located in the CUDA"):
+        mod.rnnt_loss(torch.tensor([], dtype=torch.float32), e, e, e, 0, 0.0)

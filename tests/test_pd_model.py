@@ -88,3 +88,51 @@ def test_input_check():
     assert not pm.in_range(bad)
     ok = lp2.copy(); ok[:, -1, 1] = np.nan          # label channel of the last column: not part of the lattice
     assert pm.in_range(ok)
+
+
+def _step_case(T, U, t_step, lo, hi):
+    """Label log-probs `lo` up to frame t_step and `hi` after it, blank = the rest of the mass: every log-prob is
+    well inside the input range, yet neighbouring columns of a diagonal that crosses the step differ by
+    exp((hi-lo)*u) (2^1558 at u = 120 for -10 -> -1)."""
+    lp2 = np.zeros((T, U, 2), np.float32)
+    lab = np.where(np.arange(T) <= t_step, lo, hi).astype(np.float64)
+    lp2[..., 1] = lab[:, None]
+    lp2[..., 0] = np.log1p(-np.exp(lab))[:, None]
+    return lp2
+
+
+@pytest.mark.parametrize("T,U,t_step,lo,hi", [(300, 120, 150, -10.0, -1.0), (60, 24, 30, -70.0, -1e-3)])
+def test_column_gap_beyond_fp64_is_flagged_not_silently_wrong(T, U, t_step, lo, hi):
+    """The per-column exponents may drift apart without bound while every input passes the range check; the factor
+    2**(E_left - E_own) must then not be trusted.  The model (as the kernel) flags the sweep, and the flagged result
+    is indeed wrong -- which is why the log-domain kernel redoes it."""
+    lp2 = _step_case(T, U, t_step, lo, hi)
+    assert pm.in_range(lp2)
+    al, be, ll, ok = pm.lattice(lp2)
+    assert not ok
+    _, _, a64, b64 = transduce_np.transduce(lp2.astype(np.float64), np.ones(U - 1, int), 0, 0.0, True)
+    assert np.isfinite(b64[0, 0])
+
+
+@pytest.mark.parametrize("hi", [-6.0, -4.0])
+def test_moderate_steps_are_carried_and_exact(hi):
+    """A step that keeps the column gap inside MAX_GAP is carried: same accuracy as everywhere else."""
+    T, U = 200, 60
+    lp2 = _step_case(T, U, 100, -8.0, hi)
+    al, be, ll, ok = pm.lattice(lp2)
+    assert ok
+    _, _, a64, b64 = transduce_np.transduce(lp2.astype(np.float64), np.ones(U - 1, int), 0, 0.0, True)
+    ulp = np.spacing(np.abs(a64).max().astype(np.float32))
+    bound = 0.75 * ulp + 4e-7 * np.sqrt(T + U) + 2e-7
+    assert np.abs(al - a64).max() <= bound and np.abs(be - b64).max() <= bound
+
+
+def test_nan_in_a_live_cell_is_flagged_by_the_chain():
+    """v_min3/v_max3 of the loader's full-block path skip a NaN operand; the NaN is sticky in the chain and the
+    final-value check catches it."""
+    lp2 = _pairs(40, 12, 7, 5)
+    assert pm.sweep(lp2[..., 0], lp2[..., 1])[2] and pm.sweep(lp2[..., 0], lp2[..., 1], beta=True)[2]
+    for ch in (0, 1):
+        bad = lp2.copy(); bad[20, 5, ch] = np.nan
+        assert not pm.sweep(bad[..., 0], bad[..., 1])[2]
+        assert not pm.sweep(bad[..., 0], bad[..., 1], beta=True)[2]

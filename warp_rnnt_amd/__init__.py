@@ -11,6 +11,35 @@ The drop-in package that mirrors the reference's Python interface is the
 top-level ``warp_rnnt`` (``warp_rnnt.rnnt_loss``, ``warp_rnnt._C.rnnt_loss``).
 There is no CPU fallback anywhere in these packages.
 """
+import contextlib
+
 from ._lib import load, lib_path, RNNTStatusError  # noqa: F401
+
+LATTICE_ROUTES = ("auto", "logdomain", "pd")
+
+
+def set_lattice(route):
+    """Select the arithmetic of the alpha/beta sweeps for every later call in this process (include/warp_rnnt_amd.h,
+    ``rnnt_amd_set_lattice``): ``"auto"`` (default; the probability-domain kernel on long lattices, the log-domain
+    kernel elsewhere -- fastest, results depend on the batch shape at the 1e-2 level of fp32 log-domain drift on
+    long lattices), ``"logdomain"`` (always the reference's fp32 log-sum-exp arithmetic) or ``"pd"`` (the
+    probability-domain kernel wherever it is supported).  Returns the previous route."""
+    if route not in LATTICE_ROUTES:
+        raise ValueError(f"unknown lattice route {route!r}: expected one of {LATTICE_ROUTES}")
+    return LATTICE_ROUTES[load().rnnt_amd_set_lattice(LATTICE_ROUTES.index(route))]
+
+
+def get_lattice():
+    return LATTICE_ROUTES[load().rnnt_amd_get_lattice()]
+
+
+@contextlib.contextmanager
+def lattice_route(route):
+    """``with warp_rnnt_amd.lattice_route("logdomain"): ...`` -- the route inside the block, the old one after it."""
+    old = set_lattice(route)
+    try:
+        yield
+    finally:
+        set_lattice(old)
 
 __version__ = "0.1.0"

@@ -33,6 +33,7 @@ size_t carve(void* base, int N, int T, int U, Workspace* w) {
     float* ll = reinterpret_cast<float*>(take((size_t)N * sizeof(float)));
     int* mismatch = reinterpret_cast<int*>(take((size_t)N * sizeof(int)));
     int* redo = reinterpret_cast<int*>(take(((size_t)N * 2 + 2) * sizeof(int)));   // flags, queue head, launch counter
+    // (reserved by SHAPE, never by the current route: the size of a workspace must not depend on a setting)
     unsigned long long* mail = reinterpret_cast<unsigned long long*>(take(pd_mail_bytes(N, T, U)));
     if (w) *w = Workspace{alphas, betas, ws2, ll, mismatch, redo, mail};
     return off;
@@ -50,7 +51,11 @@ bool dims_ok(int N, int T, int U) {
 
 extern "C" {
 
-int rnnt_amd_version(void) { return 100; }
+int rnnt_amd_version(void) { return 101; }
+
+int rnnt_amd_set_lattice(int route) { return set_lattice_route(route); }
+
+int rnnt_amd_get_lattice(void) { return lattice_route(); }
 
 size_t rnnt_amd_workspace_size(int N, int T, int U) {
     if (!dims_ok(N, T, U)) return 0;
@@ -140,6 +145,7 @@ rnntStatus_t rnnt_amd_loss(rnntStream_t stream, void* workspace, int input_kind,
 
     // 2. alpha / beta sweeps (2N workgroups, concurrent)
     LatticeArgs la{w.ws2, nullptr, xn, yn, w.alphas, w.betas, w.ll, T, U, 2, 0, nullptr, w.redo, w.redo + 2 * N, w.mail};
+    la.route = lattice_route();
     if (launch_lattice(stream, la, N, LOAD_SKEWED) != hipSuccess) return RNNT_STATUS_WARP_FAILED;
 
     // 3. gradients + costs (+ guard).  For a dense result the pairs are produced in place in the
@@ -167,6 +173,7 @@ rnntStatus_t rnnt_amd_debug_lattice_only(rnntStream_t stream, void* workspace, c
     Workspace w;
     carve(workspace, N, T, U, &w);
     LatticeArgs la{w.ws2, nullptr, xn, yn, w.alphas, w.betas, w.ll, T, U, 2, 0, nullptr, w.redo, w.redo + 2 * N, w.mail};
+    la.route = lattice_route();
     if (launch_lattice(stream, la, N, LOAD_SKEWED) != hipSuccess) return RNNT_STATUS_WARP_FAILED;
     return RNNT_STATUS_SUCCESS;
 }
@@ -209,6 +216,7 @@ rnntStatus_t rnnt_amd_loss_compact(rnntStream_t stream, void* workspace, const f
                               blank) != hipSuccess)
         return RNNT_STATUS_PROLOGUE_FAILED;
     LatticeArgs la{ws2, nullptr, xn, yn, alphas, betas, ll, Tmax, Umax, 2, 0, cell_offsets};
+    la.route = lattice_route();
     if (launch_lattice(stream, la, N, LOAD_SKEWED) != hipSuccess) return RNNT_STATUS_WARP_FAILED;
     GradArgs ga{ws2, nullptr, xn, yn, alphas, betas, ll, grads2 ? grads2 : ws2, costs, mismatch,
                 Tmax, Umax, 2, 0, fastemit_lambda, cell_offsets};

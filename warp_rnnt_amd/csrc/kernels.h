@@ -27,7 +27,21 @@ struct LatticeArgs {
     const unsigned* offs32;  // compact layout with the reference's 32-bit offsets (run_warp_rnnt_compact); used when
                              // offs is null
     int beta_only;        // compact shim, required_grad = false: the alpha sweep is skipped (its buffer aliases betas)
+    int route;            // LatticeRoute of this call (diagonal-major loader only); 0 = ROUTE_AUTO
 };
+
+// Which arithmetic sweeps the lattice of a diagonal-major call.  Per call: api.hip copies the process-wide setting
+// (rnnt_amd_set_lattice; initial value from the environment variable RNNT_LATTICE) into LatticeArgs::route.
+enum LatticeRoute : int {
+    ROUTE_AUTO = 0,       // probability domain where it is the faster kernel (long lattices), log domain elsewhere
+    ROUTE_LOGDOMAIN = 1,  // the reference's arithmetic: lse per cell in fp32 (lattice_ws.hip / lattice.hip)
+    ROUTE_PD = 2          // probability domain (lattice_pd.hip) wherever it is supported (padded layout, U <= 512)
+};
+int lattice_route();              // current setting
+int set_lattice_route(int route); // returns the previous setting, or -1 for an unknown value (nothing changes)
+// true when launch_lattice may hand this shape to the probability-domain kernel under SOME route: the workspace
+// then reserves its hand-over rings (a function of the shape only, so that the size never depends on the setting)
+bool pd_shape_supported(int T, int U);
 __host__ __device__ inline bool is_compact(const LatticeArgs& a) { return a.offs || a.offs32; }
 __device__ inline size_t compact_base(const LatticeArgs& a, int n) { return a.offs ? (size_t)a.offs[n] : (size_t)a.offs32[n]; }
 

@@ -27,6 +27,9 @@
 #include <cstdlib>
 #include <type_traits>
 
+#include <atomic>
+#include <cstdlib>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -442,6 +445,31 @@ __global__ void __launch_bounds__(MAXW * WAVE) k_lattice(const LatticeArgs a) {
         sweep<LOADER, false, COMPACT>(a, n, mail, trash);
 }
 
+namespace {
+int route_from_env() {
+    const char* v = getenv("RNNT_LATTICE");
+    if (v && v[0] == 'l') return ROUTE_LOGDOMAIN;
+    if (v && v[0] == 'p') return ROUTE_PD;
+    return ROUTE_AUTO;
+}
+std::atomic<int>& route_setting() {
+    static std::atomic<int> r{route_from_env()};
+    return r;
+}
+}  // namespace
+
+int lattice_route() { return route_setting().load(std::memory_order_relaxed); }
+
+int set_lattice_route(int route) {
+    if (route < ROUTE_AUTO || route > ROUTE_PD) return -1;
+    return route_setting().exchange(route, std::memory_order_relaxed);
+}
+
+bool pd_shape_supported(int T, int U) {
+    (void)T;
+    return (U + WAVE - 1) / WAVE <= 8;     // the log-domain kernel behind it must be able to redo a sweep (U <= 512)
+}
+
 hipError_t launch_lattice(hipStream_t stream, const LatticeArgs& a, int N, int loader) {
     if (N <= 0) return hipSuccess;
 #ifndef RNNT_LATTICE_LEGACY
@@ -457,13 +485,14 @@ hipError_t launch_lattice(hipStream_t stream, const LatticeArgs& a, int N, int l
         //   T=1500 U=300: N=32 166/161, N=64 254/201 (its column blocks want a CU each).
         //   (profiles/r02_lattice_probe.txt)
         // U <= 512 because the log-domain kernel behind it must be able to redo a sweep.
-        // RNNT_LATTICE=logdomain|pd overrides the choice (A/B runs, tests).
-        static const char* force = getenv("RNNT_LATTICE");
+        // The route is a per-call setting (LatticeArgs::route <- rnnt_amd_set_lattice(); the environment variable
+        // RNNT_LATTICE=logdomain|pd only provides its initial value): ROUTE_LOGDOMAIN pins the reference's
+        // arithmetic, ROUTE_PD takes the probability-domain kernel wherever it is supported.
         const int nA = (a.U + WAVE - 1) / WAVE;
-        bool use_pd = a.redo && a.queue && !is_compact(a) && nA <= 8 && (long long)2 * N * nA <= 256 && a.T >= 640 &&
-                      a.T >= 2 * a.U;
-        if (force && force[0] == 'l') use_pd = false;
-        if (force && force[0] == 'p') use_pd = a.redo && a.queue && !is_compact(a) && nA <= 8;
+        const bool pd_ok = a.redo && a.queue && !is_compact(a) && pd_shape_supported(a.T, a.U);
+        bool use_pd = pd_ok && (long long)2 * N * nA <= 256 && a.T >= 640 && a.T >= 2 * a.U;
+        if (a.route == ROUTE_LOGDOMAIN) use_pd = false;
+        if (a.route == ROUTE_PD) use_pd = pd_ok;
         if (use_pd) {
             const hipError_t e = launch_lattice_pd(stream, a, N);
             if (e == hipSuccess) return launch_lattice_ws(stream, a, N);

@@ -47,6 +47,7 @@
 //
 // Reference counterpart: core_gather.cu:37-133 (alphas), :135-234 (betas) -- 32x1 warp tiles ordered by
 // global spin locks, lse per cell.  Outputs are the same quantities (log alpha, log beta, fp32).
+#include <algorithm>
 #include <atomic>
 #include <random>
 #include <type_traits>
@@ -79,6 +80,13 @@ constexpr int GPITCH = 4 * K;       // granules reserved per block in the global
 constexpr int RSRC_WORD3 = 0x00020000;
 constexpr int OOB = (int)0x80000000;
 constexpr float P_MIN = 0x1p-115f, P_MAX = 0x1p100f;   // accepted range of an fp32 probability (see header)
+// Largest binary-exponent gap between neighbouring columns the fp64 state is trusted with.  Within one
+// renormalisation interval a value can grow by the gap of every column boundary it crosses (KR of them at most) on
+// top of its own 2^+-1008 of drift: 400 leaves two such crossings inside 2^1022, anything beyond shows up as a
+// non-finite final value, which is checked too (sweep()).  Measured gaps of sharp-model data: 2^60...2^120
+// (tests/test_pd_model.py).
+constexpr int MAX_GAP = 400;
+constexpr int GAP_CLAMP = 1000;
 constexpr float LOG2E = 1.44269504088896340736f;
 constexpr float LN2 = 0.693147180559945309417f;
 #ifndef RNNT_PD_SPIN_LIMIT
@@ -132,7 +140,14 @@ __device__ __forceinline__ int wave_shr1_i32(int first, int src) {
     return __builtin_amdgcn_update_dpp(first, src, 0x138, 0xf, 0xf, false);
 }
 
-__device__ __forceinline__ unsigned block_tag(unsigned epoch, int lb) { return epoch ^ ((unsigned)(lb + 1) * 0x9E3779B1u); }
+// Tag of block lb of one ring: launch epoch, ring (sweep and boundary) and block folded together, never 0 -- the rings
+// are cleared to zero in front of every launch (k_prepare), so a granule validates only if THIS launch wrote it,
+// whatever the workspace held before (fresh allocator memory, another shape's rings, an earlier graph replay).
+__device__ __forceinline__ unsigned ring_tag(unsigned epoch, unsigned ring) { return epoch ^ (ring * 0x85EBCA6Bu); }
+__device__ __forceinline__ unsigned block_tag(unsigned ring_epoch, int lb) {
+    const unsigned t = ring_epoch ^ ((unsigned)(lb + 1) * 0x9E3779B1u);
+    return t ? t : 1u;
+}
 
 struct Cell2 { double b, l; };   // blank / label probability of one lattice cell
 
@@ -146,7 +161,7 @@ __device__ __forceinline__ void compute_block(const Cell2 (&cur)[K], Cell2 (&nxt
                                               const int e_mail0, const int e_mail1, double& Y, double& X, int& E,
                                               const int d0, const int ucol_chk, const int Tn, const int wave_c,
                                               const float* next_probs, float* vdst, double* xdst, int* edst,
-                                              int* email_dst) {
+                                              int* email_dst, int& gap_hi, int& gap_lo) {
     double vprev = 0.0, xprev = 0.0, c = 1.0;
 #pragma unroll
     for (int k = 0; k < K; ++k) {
@@ -171,7 +186,20 @@ __device__ __forceinline__ void compute_block(const Cell2 (&cur)[K], Cell2 (&nxt
             edst[h * WAVE] = E;                               // the storer's scale for this interval's values
             if constexpr (MAIL) email_dst[h] = E;             // (lane 63's pointer; the others aim at a dump slot)
             const int e_left = wave_shr1_i32(SEED ? e_mail_h : E, E);
-            c = __builtin_ldexp(1.0, e_left - E);             // 2^(E_left - E_own); lane 0 of the first block: 1
+            // 2^(E_left - E_own); lane 0 of the first block: 1.  The gap between neighbouring columns is unbounded in
+            // principle (a frame at which the label probabilities step up puts (pL(t+1)/pL(t))^u between two columns
+            // of one diagonal: 2^1558 with every log-prob above -10) and fp64 holds 2^+-1022: the extremes of the gap
+            // are recorded (two instructions per interval) and a sweep that saw more than MAX_GAP is handed to the
+            // log-domain kernel; the shift itself is clamped so that the factor stays finite either way.
+            int gap = e_left - E;
+            if constexpr (MASKED) {
+                // a finished lane's exponent is frozen while its left neighbours' move on: not a gap of the lattice
+                const bool done = d0 + k - ucol_chk >= Tn;
+                gap = done ? 0 : gap;
+            }
+            gap_hi = max(gap_hi, gap);
+            gap_lo = min(gap_lo, gap);
+            c = __builtin_ldexp(1.0, min(max(gap, -GAP_CLAMP), GAP_CLAMP));
         }
         const double xin = X;                             // what the right neighbour reads at this step
         // the left neighbour's value: the lane to the left, or -- lane 0 of a column block that has a neighbour --
@@ -283,6 +311,9 @@ __device__ __forceinline__ void sweep(const LatticeArgs& a, const Item it, const
     const size_t sweep_id = (size_t)2 * n + (BETA ? 1 : 0);
     u64* ring_in = has_left ? a.mail + ((sweep_id * (nA - 1) + (idx - 1)) * (size_t)a.mail_blocks) * GPITCH : nullptr;
     u64* ring_out = has_right ? a.mail + ((sweep_id * (nA - 1) + idx) * (size_t)a.mail_blocks) * GPITCH : nullptr;
+    const unsigned tag_in = ring_tag(a.epoch, (unsigned)(sweep_id * (nA - 1) + (idx - 1)));
+    const unsigned tag_out = ring_tag(a.epoch, (unsigned)(sweep_id * (nA - 1) + idx));
+    (void)tag_in; (void)tag_out;
 
     const int rowb_lp = U * 8, rowb_out = U * 4;
     // row (forward diagonal mod T) of the first diagonal of block `lo`; rows advance by one per diagonal
@@ -319,6 +350,7 @@ __device__ __forceinline__ void sweep(const LatticeArgs& a, const Item it, const
         u64 mregs[NBR] = {0, 0, 0};
         constexpr bool does_mail = has_left && half == 0;  // the first loader wave also fetches the boundary column
         int row_ld = row0;
+        const bool last_column = u == Un - 1;
         float pmin = 1.0f, pmax = 1.0f;               // range of the probabilities of live cells this wave produced
         const u64* gsrc = has_left ? ring_in + (lane < GRAN ? lane : GRAN) : nullptr;   // lanes >= 17: a pad granule
         (void)gsrc; (void)mregs;
@@ -340,7 +372,7 @@ __device__ __forceinline__ void sweep(const LatticeArgs& a, const Item it, const
             return __hip_atomic_load(gsrc + (size_t)lb * GPITCH, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         };
         auto mail_valid = [&](const int lb, const u64 g) {
-            const bool ok = lane >= GRAN || (unsigned)(g >> 32) == block_tag(a.epoch, lb);
+            const bool ok = lane >= GRAN || (unsigned)(g >> 32) == block_tag(tag_in, lb);
             return __builtin_amdgcn_ballot_w64(!ok) == 0;
         };
         bool lost = false;     // a wait has timed out: the sweep is flagged for the log-domain kernel, the rest of it
@@ -383,13 +415,17 @@ __device__ __forceinline__ void sweep(const LatticeArgs& a, const Item it, const
                     const float pl = __builtin_amdgcn_exp2f(v.y * LOG2E);
 #endif
                     if (full) {
-                        asm("v_min3_f32 %0, %0, %1, %2" : "+v"(pmin) : "v"(pb), "v"(pl));
-                        asm("v_max3_f32 %0, %0, %1, %2" : "+v"(pmax) : "v"(pb), "v"(pl));
+                        // (v_min3/v_max3 skip a NaN operand: a NaN in a live cell is caught by the compute wave's
+                        //  final check instead -- it is sticky in the chain.  The label channel of the last column is
+                        //  not part of the lattice: whatever it holds is not judged.)
+                        const float pl_j = last_column ? pb : pl;
+                        asm("v_min3_f32 %0, %0, %1, %2" : "+v"(pmin) : "v"(pb), "v"(pl_j));
+                        asm("v_max3_f32 %0, %0, %1, %2" : "+v"(pmax) : "v"(pb), "v"(pl_j));
                     } else {
                         // cells outside the utterance may hold anything: they are never used, never judged;
                         // nor is the label channel of the last column
                         const bool live = (unsigned)(d0 + k - ucol_chk) < (unsigned)Tn;
-                        const float pl_j = (u == Un - 1) ? pb : pl;
+                        const float pl_j = last_column ? pb : pl;
                         if (live) {
                             pmin = __builtin_fminf(pmin, __builtin_fminf(pb, pl_j));
                             pmax = __builtin_fmaxf(pmax, __builtin_fmaxf(pb, pl_j));
@@ -457,7 +493,7 @@ __device__ __forceinline__ void sweep(const LatticeArgs& a, const Item it, const
             const int ps = p - 3;
             if (!GUARDED || (ps >= lo && ps < hi)) {
                 if (has_right && half == 0 && lane < GRAN) {      // (has_right: compile time)
-                    const u64 g = ((u64)block_tag(a.epoch, ps) << 32) | sm.mail_out[ps & (MSLOTS - 1)][lane];
+                    const u64 g = ((u64)block_tag(tag_out, ps) << 32) | sm.mail_out[ps & (MSLOTS - 1)][lane];
                     __hip_atomic_store(ring_out + (size_t)ps * GPITCH + lane, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
                 const float* src = &sm.vals[ps & (VSLOTS - 1)][lane * VSTRIDE + 2 * k0];
@@ -519,6 +555,7 @@ __device__ __forceinline__ void sweep(const LatticeArgs& a, const Item it, const
     double Y = (ucol == 0) ? 1.0 : 0.0;
     double X = 0.0;
     int E = 0;
+    int gap_hi = 0, gap_lo = 0;      // extremes of E_left - E_own over the renormalisations of this column block
     Cell2 bufA[K], bufB[K];
     auto do_block = [&](const int lb, const Cell2 (&cur)[K], Cell2 (&nxt)[K]) {
         const int d0 = lb * K;
@@ -544,7 +581,7 @@ __device__ __forceinline__ void sweep(const LatticeArgs& a, const Item it, const
         const bool full = full_block(lb);
 #define RNNT_PD_CALL(MASKED, SEED, MAIL)                                                                          \
     compute_block<BETA, MASKED, SEED, MAIL>(cur, nxt, seed, e_mail0, e_mail1, Y, X, E, d0, ucol_chk, Tn, wave_c, \
-                                            next_probs, vdst, xdst, edst, email_dst)
+                                            next_probs, vdst, xdst, edst, email_dst, gap_hi, gap_lo)
         if (full) RNNT_PD_CALL(false, HAS_LEFT, HAS_RIGHT);
         else RNNT_PD_CALL(true, HAS_LEFT, HAS_RIGHT);
 #undef RNNT_PD_CALL
@@ -567,6 +604,12 @@ __device__ __forceinline__ void sweep(const LatticeArgs& a, const Item it, const
         do_block(lb + 1, bufB, bufA);
     }
     if (lb < hi) { do_block(lb, bufA, bufB); ++lb; }
+    // Range check of the chain, after the fact (nothing in the steady-state loop): a column boundary wider than the
+    // fp64 state is trusted with, or a final value that is not a positive finite number -- an overflowed factor,
+    // a NaN or a total underflow anywhere upstream is sticky in Y (every weight is a non-negative probability, nothing
+    // ever subtracts) -- hands the sweep to the log-domain kernel.  Lanes beyond the last column carry garbage by
+    // design and are not judged.
+    if (colvalid && (gap_hi > MAX_GAP || gap_lo < -MAX_GAP || !(Y > 0.0 && Y < __builtin_inf()))) *wg_bad = 1;
     for (g = (lb - lo) + 2 + DLOAD; g < G; ++g) block_barrier();
     if constexpr (!BETA) {
         // the finished last column holds (alpha * pB)(T-1,U-1) in Y: the alpha-side log-likelihood
@@ -579,8 +622,8 @@ template <bool COMPACT>
 __global__ void __launch_bounds__(5 * WAVE) k_lattice_pd(LatticeArgs a, const int nA) {
     __shared__ Smem sm;
     __shared__ int wg_bad, s_item;
-    // launch epoch = host counter (constant across the replays of a captured graph) + device counter (queue[1],
-    // bumped by k_prepare in front of every launch, replayed or not)
+    // launch epoch = host counter (constant across the replays of a captured graph) + device counter (queue[1]: the
+    // library's own per-device launch counter, bumped by k_prepare in front of every launch, replayed or not)
 #ifndef RNNT_PD_FROZEN_EPOCH      // (defined only to show that tests/test_gpu_graph.py fails without the counter)
     a.epoch += (unsigned)a.queue[1];
 #endif
@@ -611,12 +654,23 @@ __global__ void __launch_bounds__(5 * WAVE) k_lattice_pd(LatticeArgs a, const in
     if (threadIdx.x == 0 && wg_bad) atomicOr(&a.redo[2 * it.n + it.dir], wg_bad);
 }
 
-// Clears the redo flags and the queue head (n words) and bumps the launch counter behind them (p[n]).  The counter
-// lives in the workspace so that every REPLAY of a captured graph gets a fresh epoch too -- kernel arguments are
-// frozen at capture time, and with a frozen epoch the granules of the previous replay would validate.
-__global__ void __launch_bounds__(256) k_prepare(int* p, int n) {
-    for (int i = threadIdx.x; i < n; i += 256) p[i] = 0;
-    if (threadIdx.x == 0) p[n] = p[n] + 1;
+// The library's launch counter of this device: module-scope device memory (zero when the code object is loaded,
+// never part of anybody's workspace), so it cannot be recycled, scribbled over or left uninitialised, and every
+// REPLAY of a captured graph advances it too -- kernel arguments are frozen at capture time, and with a frozen
+// epoch the granules of the previous replay would carry this replay's tags.
+__device__ unsigned g_launch_counter;
+
+// In front of every launch: clears the redo flags and the queue head (n words), hands the next value of the launch
+// counter to the kernel (p[n]) and zeroes the hand-over rings (mail_vec 16-byte words; tag 0 never validates), so
+// that nothing the workspace held before -- it is caller scratch with unspecified contents -- can be taken for a
+// granule of this launch.  The clear is 2 % of the bytes the sweeps move and rides on a launch that existed anyway.
+__global__ void __launch_bounds__(256) k_prepare(int* p, int n, uint4* mail, size_t mail_vec) {
+    if (blockIdx.x == 0) {
+        for (int i = threadIdx.x; i < n; i += 256) p[i] = 0;
+        if (threadIdx.x == 0) p[n] = (int)(atomicAdd(&g_launch_counter, 1u) + 1u);
+    }
+    const uint4 z = make_uint4(0, 0, 0, 0);
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < mail_vec; i += (size_t)gridDim.x * 256) mail[i] = z;
 }
 
 }  // namespace pd
@@ -625,7 +679,7 @@ size_t pd_mail_blocks(int T, int U) { return (size_t)(T + U - 1 + pd::K - 1) / p
 
 size_t pd_mail_bytes(int N, int T, int U) {
     const int nA = (U + WAVE - 1) / WAVE;
-    if (nA < 2) return 0;
+    if (nA < 2 || !pd_shape_supported(T, U)) return 0;     // one column block, or a shape the kernel never takes
     return (size_t)2 * N * (nA - 1) * pd_mail_blocks(T, U) * pd::GPITCH * sizeof(pd::u64);
 }
 
@@ -644,7 +698,9 @@ hipError_t launch_lattice_pd(hipStream_t stream, const LatticeArgs& a0, int N) {
     a.mail_blocks = (int)pd_mail_blocks(a.T, a.U);
     // redo (2N ints) and the queue head are contiguous in the workspace (api.hip: carve).  One tiny kernel:
     // hipMemsetAsync of these few bytes becomes two fill kernels of ~5 us each.
-    pd::k_prepare<<<1, 256, 0, stream>>>(a.redo, 2 * N + 1);
+    const size_t mail_vec = nA > 1 ? (size_t)2 * N * (nA - 1) * a.mail_blocks * pd::GPITCH * sizeof(pd::u64) / 16 : 0;
+    const unsigned prep_blocks = (unsigned)std::min<size_t>(512, std::max<size_t>(1, mail_vec / (256 * 8)));
+    pd::k_prepare<<<prep_blocks, 256, 0, stream>>>(a.redo, 2 * N + 1, reinterpret_cast<uint4*>(a.mail), mail_vec);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     const dim3 grid(2 * N * nA), block(5 * WAVE);

@@ -653,8 +653,12 @@ k_to_diagonal(const float* __restrict__ src, const int* __restrict__ labels, flo
         if (t < T && u < U) {
             const size_t cell = nbase + (size_t)t * U + u;
             if constexpr (DENSE) {
+                // Two dwords of a 4V-byte row: the memory system fetches whole 128-byte lines (a one-dword-per-line
+                // probe over the same tensor takes as long as reading all of it, tools/ubench/gather_variants.hip),
+                // so this kernel streams ~1.4 lines per cell and none of them is touched again: non-temporal loads
+                // (206 vs 227 us for the probe, 205-229 vs 227-255 us here, box to box).
                 const float* p = src + cell * (size_t)V;
-                tile[tl][ul] = make_float2(p[blank], p[lab]);
+                tile[tl][ul] = make_float2(__builtin_nontemporal_load(p + blank), __builtin_nontemporal_load(p + lab));
             } else {
                 tile[tl][ul] = reinterpret_cast<const float2*>(src)[cell];
             }
