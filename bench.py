@@ -50,6 +50,9 @@ def parse():
     p.add_argument("--dry", action="store_true",
                    help="CPU rehearsal of the launcher + process group + reduction + JSON line: no kernels run, "
                         "nothing is measured (tests/test_host_cpu.py)")
+    p.add_argument("--rccl-group", action="store_true",
+                   help="with --gpus 1 and no launcher: still create a real one-rank RCCL process group, so that the "
+                        "step carries the per-step all-reduce leg of the multi-GPU path (profiles/r03_rccl_leg.txt)")
     p.add_argument("--global-batch", type=int, default=0,
                    help="strong scaling: fix the GLOBAL number of utterances and shard it over the ranks "
                         "(default 0 = weak scaling, the config's per-GPU batch on every rank)")
@@ -183,10 +186,16 @@ def main():
     torch.cuda.set_device(dev)
     dist = None
     rccl_ranks = 1
-    if world > 1 or "TORCHELASTIC_RUN_ID" in os.environ:   # under torch.distributed.run even a 1-rank group is real
+    if world > 1 or "TORCHELASTIC_RUN_ID" in os.environ or a.rccl_group:
+        # under torch.distributed.run (or with --rccl-group) even a 1-rank group is a real RCCL communicator
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if "MASTER_PORT" not in os.environ:
+            import socket
+            with socket.socket() as s:
+                s.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(s.getsockname()[1])
+        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
 
     from warp_rnnt_amd import _build
     _build.ensure_built()              # no-op when the prebuilt library travelled with the tree
@@ -376,6 +385,7 @@ def main():
                                    "frac": round(g_achieved / HBM_PEAK_GBS, 4), "traffic": None,
                                    "algorithmic_bytes": g_bytes, "kernels_ms": round(g_ms, 4)},
             "rccl_ranks": rccl_ranks,
+            "rccl_group": dist is not None,     # True: every step ended in costs.sum() + one RCCL all-reduce
         }
         out.update(extras)
         if not a.no_cpu_baseline and world == 1:   # the CPU leg is reported at N=1 only
