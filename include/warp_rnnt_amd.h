@@ -86,8 +86,11 @@ rnntStatus_t run_warp_rnnt_gather(rnntStream_t stream, unsigned int *counts, flo
  * own names and argument lists, so that pytorch_binding/binding.cpp (:170, :197, :241) links against this
  * library whole.  As there: void return, work is enqueued on the NULL stream, every pointer is a device pointer,
  * memPref / labelPref are the (N,) EXCLUSIVE prefix sums of xn*(yn+1) and yn (binding.cpp:147-160), counts holds
- * at least 2N words.  Not as there: a failed launch is not exit(-1) (core.h:7-14) but is remembered per host
- * thread and returned (and cleared) by rnnt_amd_compact_last_status(); lengths with xn < 1 give cost NaN and
+ * at least 2N words.  Not as there: a failure (a launch error, or sizes this library does not take: N > 65535,
+ * N*T*U >= 2^32) is not exit(-1) (core.h:7-14) but is reported three ways, because the reference's binding checks
+ * none: a line on stderr, costs filled with NaN (so that an unchecked caller sees a NaN loss, not uninitialised
+ * memory), and a per-host-thread status returned (and cleared) by rnnt_amd_compact_last_status() -- poll it after
+ * run_warp_rnnt_compact if you can.  Lengths with xn < 1 give cost NaN and
  * touch nothing; required_grad == 0 computes betas and costs only and never writes alphas / grads (the reference
  * aliases both to betas then, binding.cpp:192-195).  Gradients honour the alpha/beta consistency guard of the
  * padded kernels (core_gather.cu:341-354), which the reference's compact kernels lack.

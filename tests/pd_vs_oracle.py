@@ -120,8 +120,9 @@ def main():
         #  hardware exp2/log2 on the GPU, libm in the oracle -- does not average out along the sweep: 2e-5 relative
         #  on the cost at T+U = 900, where random inputs give 1e-6)
         np.testing.assert_allclose(c, ref["costs"], rtol=1e-4, err_msg=f"step case {T}x{U}")
-        np.testing.assert_allclose(g, ref["grads"], atol=5e-4 * max(1.0, float(np.abs(ref["costs"]).max()) / 100.0),
-                                   err_msg=f"step case {T}x{U}")
+        # (... and one to one on the gradients: 1.4e-3 at T+U = 900; the failure this guards against is garbage --
+        #  log-likelihood -374 for -88 in the model of the unchecked kernel)
+        np.testing.assert_allclose(g, ref["grads"], atol=3e-3, err_msg=f"step case {T}x{U}")
         flags = redo_flags(lp2, xn, yn)
         # the ALPHA sweeps cross the step upwards (flags[2n]); the beta sweeps meet it downwards, where every column
         # can still emit its remaining labels in the cheap frames and neighbours stay within e per column: those
@@ -139,7 +140,7 @@ def main():
     ref = oracle.rnnt_loss_f32(lp2, None, xn, yn, blank=-1, scan_mode=1)
     c, g = native(lp2, xn, yn)
     np.testing.assert_allclose(c, ref["costs"], rtol=1e-4)
-    np.testing.assert_allclose(g, ref["grads"], atol=5e-4 * max(1.0, float(np.abs(ref["costs"]).max()) / 100.0))
+    np.testing.assert_allclose(g, ref["grads"], atol=3e-3)
     assert (redo_flags(lp2, xn, yn)[1::2] & 1).all()
     lpg = np.full((3, 1, 4, 2), -1.0, dtype=np.float32)
     lpg[1, 0, :, 1] = [3e8, -7.0, -3e8, 0.0]

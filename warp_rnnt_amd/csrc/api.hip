@@ -2,6 +2,8 @@
 // Host-side orchestration only: argument checks, workspace carving, launches.
 #include "../../include/warp_rnnt_amd.h"
 
+#include <cstdio>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -246,6 +248,18 @@ rnntStatus_t rnnt_amd_compact_scatter_grads(rnntStream_t stream, const float* gr
 // ---------------------------------------------------------------------------------------------------------
 static thread_local rnntStatus_t g_compact_status = RNNT_STATUS_SUCCESS;
 
+// A void entry point has failed: remember the status for rnnt_amd_compact_last_status(), say so on stderr (the
+// reference's CHECK_KERNEL_STAT prints and exits, core.h:7-14; its binding never looks at a status) and make the
+// failure impossible to miss downstream: costs become NaN (best effort, NULL stream like everything here) instead
+// of whatever torch.empty held, so a training loop that ignores the status stops on a NaN loss rather than
+// learning from uninitialised memory.
+static void compact_fail(rnntStatus_t st, const char* what, float* costs, unsigned int N) {
+    g_compact_status = st;
+    fprintf(stderr, "%s failed: rnnt status %d (%s)\n", what, (int)st,
+            st == RNNT_STATUS_INVALID_ARGUMENT ? "invalid argument or unsupported size" : hipGetErrorString(hipGetLastError()));
+    if (costs && N) (void)hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(costs), 0x7fc00000, N, nullptr);
+}
+
 rnntStatus_t rnnt_amd_compact_last_status(void) {
     const rnntStatus_t s = g_compact_status;
     g_compact_status = RNNT_STATUS_SUCCESS;
@@ -257,10 +271,10 @@ void run_gather_for_compact(const float* xs, const int* ys, const unsigned int* 
                             const unsigned int* labelPref, unsigned int N, unsigned int T, unsigned int U,
                             unsigned int V, unsigned int blank) {
     static_assert(sizeof(long) == sizeof(int64_t), "loc is the reference's `long` (at::kLong)");
-    if (V < 1 || blank >= V) { g_compact_status = RNNT_STATUS_INVALID_ARGUMENT; return; }
+    if (V < 1 || blank >= V) { compact_fail(RNNT_STATUS_INVALID_ARGUMENT, "run_gather_for_compact", nullptr, 0); return; }
     if (launch_gather_compact_rowmajor(nullptr, xs, ys, xn, yn, gather_xs, reinterpret_cast<int64_t*>(loc), memPref,
                                        labelPref, N, T, U, V, blank) != hipSuccess)
-        g_compact_status = RNNT_STATUS_PROLOGUE_FAILED;
+        compact_fail(RNNT_STATUS_PROLOGUE_FAILED, "run_gather_for_compact", nullptr, 0);
 }
 
 void run_warp_rnnt_compact(unsigned int* counts, float* alphas, float* betas, const float* log_probs, float* grads,
@@ -269,7 +283,10 @@ void run_warp_rnnt_compact(unsigned int* counts, float* alphas, float* betas, co
                            unsigned int T, unsigned int U, float fastemit_lambda, bool required_grad) {
     (void)labelPref;
     if (N == 0) return;
-    if (!dims_ok((int)N, T > 0 ? (int)T : 1, U > 0 ? (int)U : 1)) { g_compact_status = RNNT_STATUS_INVALID_ARGUMENT; return; }
+    if (!dims_ok((int)N, T > 0 ? (int)T : 1, U > 0 ? (int)U : 1)) {
+        compact_fail(RNNT_STATUS_INVALID_ARGUMENT, "run_warp_rnnt_compact", costs, N);
+        return;
+    }
     const int* ixn = reinterpret_cast<const int*>(xn);
     const int* iyn = reinterpret_cast<const int*>(yn);
     // counts (2*sum(yn) + 2N words, binding.cpp:187): the first N hold the alpha-side log-likelihoods
@@ -277,26 +294,29 @@ void run_warp_rnnt_compact(unsigned int* counts, float* alphas, float* betas, co
     LatticeArgs la{log_probs, nullptr, ixn, iyn, alphas, betas, ll, (int)T, (int)U, 2, 0};
     la.offs32 = memPref;
     la.beta_only = required_grad ? 0 : 1;
-    if (launch_lattice(nullptr, la, (int)N, LOAD_ROWMAJOR2) != hipSuccess) { g_compact_status = RNNT_STATUS_WARP_FAILED; return; }
+    if (launch_lattice(nullptr, la, (int)N, LOAD_ROWMAJOR2) != hipSuccess) {
+        compact_fail(RNNT_STATUS_WARP_FAILED, "run_warp_rnnt_compact", costs, N);
+        return;
+    }
     if (!required_grad) {   // the reference's "beta only" inference mode: costs from beta[0,0], nothing else is touched
         if (launch_costs_from_betas(nullptr, betas, memPref, ixn, iyn, costs, (int)N) != hipSuccess)
-            g_compact_status = RNNT_STATUS_COSTS_FAILED;
+            compact_fail(RNNT_STATUS_COSTS_FAILED, "run_warp_rnnt_compact", costs, N);
         return;
     }
     GradArgs ga{log_probs, nullptr, ixn, iyn, alphas, betas, ll, grads, costs, nullptr, (int)T, (int)U, 2, 0,
                 fastemit_lambda};
     ga.offs32 = memPref;
     if (launch_grads(nullptr, ga, (int)N, LOAD_ROWMAJOR2, WRITE_ROWMAJOR2) != hipSuccess)
-        g_compact_status = RNNT_STATUS_GRADS_BLANK_FAILED;
+        compact_fail(RNNT_STATUS_GRADS_BLANK_FAILED, "run_warp_rnnt_compact", costs, N);
 }
 
 void run_scatter_grad_for_compact(const float* grad_cost, const float* gather_grad, const long* loc,
                                   const int* cum_lens, float* scatter_grad, unsigned int STU, unsigned int N,
                                   unsigned int V, unsigned int blank) {
-    if (V < 1 || blank >= V) { g_compact_status = RNNT_STATUS_INVALID_ARGUMENT; return; }
+    if (V < 1 || blank >= V) { compact_fail(RNNT_STATUS_INVALID_ARGUMENT, "run_scatter_grad_for_compact", nullptr, 0); return; }
     if (launch_scatter_compact(nullptr, grad_cost, gather_grad, reinterpret_cast<const int64_t*>(loc), cum_lens,
                                scatter_grad, (int64_t)STU, (int)N, (int)V, (int)blank) != hipSuccess)
-        g_compact_status = RNNT_STATUS_EXPAND_FAILED;
+        compact_fail(RNNT_STATUS_EXPAND_FAILED, "run_scatter_grad_for_compact", nullptr, 0);
 }
 
 rnntStatus_t rnnt_amd_expand_grads(rnntStream_t stream, const float* grads_diagonal, const int* labels,

@@ -381,7 +381,7 @@ __device__ __forceinline__ void sweep(const LatticeArgs& a, const Item it, const
             for (int spins = 0;; ++spins) {
                 const u64 g = mail_request(lb);
                 if (lost || mail_valid(lb, g)) return g;
-                if (spins >= SPIN_LIMIT) { *wg_bad = 2; lost = true; return g; }
+                if (spins >= SPIN_LIMIT) { atomicOr(wg_bad, 2); lost = true; return g; }
                 __builtin_amdgcn_s_sleep(8);
             }
         };
@@ -469,7 +469,7 @@ __device__ __forceinline__ void sweep(const LatticeArgs& a, const Item it, const
         }
         for (; p < p_end; ++p) l_any(p, std::true_type{});
         // input check: one flag per workgroup, read after the last barrier
-        if (colvalid && !(pmin >= P_MIN && pmax <= P_MAX)) *wg_bad = 1;      // benign race: every writer stores non-zero
+        if (colvalid && !(pmin >= P_MIN && pmax <= P_MAX)) atomicOr(wg_bad, 1);   // (LDS atomic: the reasons are bits)
         for (int g = p - (lo - DLOAD); g < G; ++g) block_barrier();
         static_assert(NBR == 3 && PSLOTS == 2 && MSLOTS == 2, "l_step phases are written for these ring depths");
     };
@@ -609,7 +609,7 @@ __device__ __forceinline__ void sweep(const LatticeArgs& a, const Item it, const
     // a NaN or a total underflow anywhere upstream is sticky in Y (every weight is a non-negative probability, nothing
     // ever subtracts) -- hands the sweep to the log-domain kernel.  Lanes beyond the last column carry garbage by
     // design and are not judged.
-    if (colvalid && (gap_hi > MAX_GAP || gap_lo < -MAX_GAP || !(Y > 0.0 && Y < __builtin_inf()))) *wg_bad = 1;
+    if (colvalid && (gap_hi > MAX_GAP || gap_lo < -MAX_GAP || !(Y > 0.0 && Y < __builtin_inf()))) atomicOr(wg_bad, 1);
     for (g = (lb - lo) + 2 + DLOAD; g < G; ++g) block_barrier();
     if constexpr (!BETA) {
         // the finished last column holds (alpha * pB)(T-1,U-1) in Y: the alpha-side log-likelihood
