@@ -160,19 +160,40 @@ def dry_run(a, world, rank):
     dist.barrier()
     ranks = dist.get_world_size()
     if rank == 0:
-        print(json.dumps({"metric": "dry run (launcher / process group / reduction only, nothing measured)",
+        emit(json.dumps({"metric": "dry run (launcher / process group / reduction only, nothing measured)",
                           "value": None, "unit": "utterances/s", "n_gpus": world, "steps": a.steps,
                           "warmup": a.warmup, "ms_per_step": None, "higher_is_better": True, "scaling": "weak",
                           "dry": True, "backend": "gloo", "rccl_ranks": ranks,
                           "reduced_scalar": float(total.item()),
-                          "config": {"workload": f"{a.config}: N={N}/rank (global {N * world})"}}), flush=True)
+                          "config": {"workload": f"{a.config}: N={N}/rank (global {N * world})"}}))
     dist.destroy_process_group()
+
+
+_STDOUT_FD = None
+
+
+def claim_stdout():
+    """The driver reads ONE JSON line from stdout.  RCCL prints its version banner to C stdout when the first
+    communicator is created (buffered, so it lands after Python's own output): everything that writes to file
+    descriptor 1 from here on goes to stderr, and the JSON line is written to the original descriptor at the end."""
+    global _STDOUT_FD
+    sys.stdout.flush()
+    _STDOUT_FD = os.dup(1)
+    os.dup2(2, 1)
+
+
+def emit(line):
+    if _STDOUT_FD is None:
+        print(line, flush=True)
+    else:
+        os.write(_STDOUT_FD, (line + "\n").encode())
 
 
 def main():
     a = parse()
     if "WORLD_SIZE" not in os.environ and a.gpus > 1:
         sys.exit(self_launch(a))
+    claim_stdout()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -394,7 +415,7 @@ def main():
                 out["cpu_baseline"] = None
             else:
                 out["cpu_baseline"] = cpu_baseline(cfg, utts)
-        print(json.dumps(out), flush=True)
+        emit(json.dumps(out))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
