@@ -173,7 +173,10 @@ rnntStatus_t rnnt_amd_expand_grads(rnntStream_t stream, const float *grads_diago
  *   grads2 (STU,2) [blank,label] gradients, fully written (NULL = costs only);
  *   loc (STU,) int64 vocabulary index of the label channel per row (NULL = not wanted).
  */
-size_t rnnt_amd_workspace_size_compact(int N, int64_t STU);
+/* Scratch for rnnt_amd_loss_compact with the same N, STU, Tmax, Umax (0 = these sizes are not supported).
+ * (Since version 102 the launch bounds are arguments: the probability-domain lattice kernel keeps its
+ * hand-over rings here too, and their size depends on Tmax and Umax.) */
+size_t rnnt_amd_workspace_size_compact(int N, int64_t STU, int Tmax, int Umax);
 /* One launch for what binding.cpp:139-170 does with a chain of tensor ops: cell_offsets (N+1,) int64 and
  * label_offsets (N+1,) int32 exclusive prefix sums of xn*(yn+1) and yn, and
  * stats[4] (device, int64) = {sum of cells (= STU), sum of yn, max xn, max yn} -- the caller reads

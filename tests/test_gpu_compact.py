@@ -230,3 +230,42 @@ def test_reference_named_compact_entry_points():
     # bad arguments are reported, not fatal
     L.run_scatter_grad_for_compact(None, None, None, None, None, 1, 1, 3, 7)
     assert L.rnnt_amd_compact_last_status() == 5 and L.rnnt_amd_compact_last_status() == 0
+
+
+@pytest.mark.parametrize("route", ["logdomain", "pd", "auto"])
+@pytest.mark.parametrize("N,Tm,Um,V,lam", [
+    (3, 40, 12, 9, 0.0),          # one column block
+    (3, 70, 150, 5, 0.02),        # three column blocks, ragged ends in different blocks
+    (2, 700, 200, 6, 0.0),        # long lattice: what "auto" hands to the probability-domain kernel
+    (5, 9, 1, 4, 0.0),            # no labels at all
+])
+def test_compact_on_both_lattice_routes(route, N, Tm, Um, V, lam):
+    """The compact layout runs on either lattice arithmetic (round 3: the probability-domain kernel's COMPACT
+    instantiation, its hand-over rings sized by the launch bounds Tmax / Umax): gathered (STU,2) gradients and costs
+    against the fp32 oracle on every route, and identical costs-only results."""
+    import warp_rnnt_amd
+    from warp_rnnt_amd import ops
+    logits, labels, xn, yn = make_case(500 + Tm + Um, N, Tm, Um, V, ragged=True)
+    lp = np_log_softmax32(logits)
+    ref = oracle.rnnt_loss_f32(lp, labels, xn, yn, fastemit_lambda=lam, scan_mode=1)
+    xs, ys = pack(lp, labels, xn, yn)
+    with warp_rnnt_amd.lattice_route(route):
+        costs, grads2, loc = ops.loss_compact(T(xs), T(ys), T(xn), T(yn), 0, lam)
+        c_only, g_none, _ = ops.loss_compact(T(xs), T(ys), T(xn), T(yn), 0, lam, required_grad=False)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(costs.cpu().numpy(), ref["costs"], rtol=1e-5)
+    np.testing.assert_array_equal(c_only.cpu().numpy(), costs.cpu().numpy())
+    assert g_none is None
+    # the oracle's dense gradient, reduced to the (blank, label) pair of every live cell in packing order
+    want = []
+    for n in range(N):
+        tn, un = int(xn[n]), int(yn[n]) + 1
+        g = ref["grads"][n, :tn, :un]                       # (tn, un, V)
+        pair = np.zeros((tn, un, 2), np.float32)
+        pair[..., 0] = g[..., 0]
+        if un > 1:
+            pair[:, :un - 1, 1] = np.take_along_axis(g[:, :un - 1], labels[n, :un - 1][None, :, None].astype(np.int64),
+                                                     axis=2)[..., 0]
+        want.append(pair.reshape(-1, 2))
+    atol = 1e-4 * max(1.0, float(np.abs(ref["costs"]).max()) / 100.0)     # (fp32 noise of the oracle grows with |loglik|)
+    np.testing.assert_allclose(grads2.cpu().numpy(), np.concatenate(want), atol=atol)

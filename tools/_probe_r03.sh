@@ -1,10 +1,10 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/r03
-for rep in 1 2; do
-for sh in 16,1500,300 16,1500,64 16,1500,512; do
-  for v in r02 hard main; do
-    RNNT_LATTICE=pd python tools/lattice_probe.py --shape $sh $v: 2>&1 | grep median | sed "s/^/N,T,U=$sh lattice=pd  /"
+(timeout 700 python -m pytest tests/test_gpu_compact.py tests/test_gpu_pd.py -q 2>&1 | tail -25) > gpurun_out/r03/pytest_compact.log
+cat gpurun_out/r03/pytest_compact.log | cut -c1-400
+for l in warp-rnnt-compact; do
+  for r in auto logdomain; do
+    RNNT_LATTICE=$r timeout 300 python tools/benchmark_table.py --loss $l --random_length True 2>&1 | tail -25 > gpurun_out/r03/table_compact_$r.txt
   done
 done
-done > gpurun_out/r03/lattice_probe2.txt
-cat gpurun_out/r03/lattice_probe2.txt
+paste gpurun_out/r03/table_compact_auto.txt gpurun_out/r03/table_compact_logdomain.txt | cut -c1-250

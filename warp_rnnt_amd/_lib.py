@@ -40,7 +40,7 @@ SYMBOLS = {
     "rnnt_amd_log_softmax": (_i, [_vp, _vp, _vp, _i64, _i]),
     "rnnt_amd_log_softmax_backward": (_i, [_vp, _vp, _vp, _vp, _i64, _i]),
     "rnnt_amd_gather": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i]),
-    "rnnt_amd_workspace_size_compact": (_sz, [_i, _i64]),
+    "rnnt_amd_workspace_size_compact": (_sz, [_i, _i64, _i, _i]),
     "rnnt_amd_loss_compact": (_i, [_vp] * 11 + [_i, _i64, _i, _i, _i, _i, _f]),
     "rnnt_amd_compact_scatter_grads": (_i, [_vp] * 6 + [_i64, _i, _i, _i]),
     "rnnt_amd_compact_offsets": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp]),

@@ -53,7 +53,7 @@ bool dims_ok(int N, int T, int U) {
 
 extern "C" {
 
-int rnnt_amd_version(void) { return 101; }
+int rnnt_amd_version(void) { return 102; }
 
 int rnnt_amd_set_lattice(int route) { return set_lattice_route(route); }
 
@@ -180,9 +180,38 @@ rnntStatus_t rnnt_amd_debug_lattice_only(rnntStream_t stream, void* workspace, c
     return RNNT_STATUS_SUCCESS;
 }
 
-size_t rnnt_amd_workspace_size_compact(int N, int64_t STU) {
-    if (N < 0 || N > 65535 || STU < 0 || STU >= ((int64_t)1 << 32)) return 0;
-    return align_up((size_t)STU * 4) * 2 + align_up((size_t)STU * 8) + align_up((size_t)N * 4) * 2 + ALIGN;
+namespace {
+struct CompactWorkspace {
+    float* alphas;
+    float* betas;
+    float* ws2;
+    float* ll;
+    int* mismatch;
+    int* redo;                  // as Workspace::redo
+    unsigned long long* mail;   // as Workspace::mail, sized by the launch bounds (Tmax, Umax)
+};
+size_t carve_compact(void* base, int N, int64_t STU, int Tmax, int Umax, CompactWorkspace* w) {
+    size_t off = 0;
+    char* p = static_cast<char*>(base);
+    auto take = [&](size_t bytes) { size_t o = off; off += align_up(bytes); return p ? p + o : nullptr; };
+    float* alphas = reinterpret_cast<float*>(take((size_t)STU * 4));
+    float* betas = reinterpret_cast<float*>(take((size_t)STU * 4));
+    float* ws2 = reinterpret_cast<float*>(take((size_t)STU * 8));
+    float* ll = reinterpret_cast<float*>(take((size_t)N * 4));
+    int* mismatch = reinterpret_cast<int*>(take((size_t)N * 4));
+    int* redo = reinterpret_cast<int*>(take(((size_t)N * 2 + 2) * sizeof(int)));
+    unsigned long long* mail = reinterpret_cast<unsigned long long*>(take(pd_mail_bytes(N, Tmax, Umax)));
+    if (w) *w = CompactWorkspace{alphas, betas, ws2, ll, mismatch, redo, mail};
+    return off + ALIGN;
+}
+bool compact_dims_ok(int N, int64_t STU, int Tmax, int Umax) {
+    return dims_ok(N, Tmax > 0 ? Tmax : 1, Umax > 0 ? Umax : 1) && STU >= 0 && STU < ((int64_t)1 << 32);
+}
+}  // namespace
+
+size_t rnnt_amd_workspace_size_compact(int N, int64_t STU, int Tmax, int Umax) {
+    if (!compact_dims_ok(N, STU, Tmax, Umax)) return 0;
+    return carve_compact(nullptr, N, STU, Tmax > 0 ? Tmax : 1, Umax > 0 ? Umax : 1, nullptr);
 }
 
 // Device-side preparation of a compact batch (offsets + launch bounds), one launch.
@@ -203,21 +232,18 @@ rnntStatus_t rnnt_amd_loss_compact(rnntStream_t stream, void* workspace, const f
                                    const int* label_offsets, float* costs, float* grads2, int64_t* loc,
                                    int N, int64_t STU, int Tmax, int Umax, int V, int blank,
                                    float fastemit_lambda) {
-    if (!dims_ok(N, Tmax > 0 ? Tmax : 1, Umax > 0 ? Umax : 1) || !workspace || V < 1 || blank < 0 || blank >= V)
+    if (!compact_dims_ok(N, STU, Tmax, Umax) || !workspace || V < 1 || blank < 0 || blank >= V)
         return RNNT_STATUS_INVALID_ARGUMENT;
-    if (STU < 0 || STU >= ((int64_t)1 << 32)) return RNNT_STATUS_INVALID_ARGUMENT;
     if (reinterpret_cast<uintptr_t>(workspace) % ALIGN) return RNNT_STATUS_INVALID_ARGUMENT;
     if (N == 0 || STU == 0) return RNNT_STATUS_SUCCESS;
-    char* p = static_cast<char*>(workspace);
-    float* alphas = reinterpret_cast<float*>(p); p += align_up((size_t)STU * 4);
-    float* betas = reinterpret_cast<float*>(p); p += align_up((size_t)STU * 4);
-    float* ws2 = reinterpret_cast<float*>(p); p += align_up((size_t)STU * 8);
-    float* ll = reinterpret_cast<float*>(p); p += align_up((size_t)N * 4);
-    int* mismatch = reinterpret_cast<int*>(p);
+    CompactWorkspace w;
+    carve_compact(workspace, N, STU, Tmax > 0 ? Tmax : 1, Umax > 0 ? Umax : 1, &w);
+    float *alphas = w.alphas, *betas = w.betas, *ws2 = w.ws2, *ll = w.ll;
+    int* mismatch = w.mismatch;
     if (launch_gather_compact(stream, xs, ys, xn, yn, cell_offsets, label_offsets, ws2, loc, N, Tmax, Umax, V,
                               blank) != hipSuccess)
         return RNNT_STATUS_PROLOGUE_FAILED;
-    LatticeArgs la{ws2, nullptr, xn, yn, alphas, betas, ll, Tmax, Umax, 2, 0, cell_offsets};
+    LatticeArgs la{ws2, nullptr, xn, yn, alphas, betas, ll, Tmax, Umax, 2, 0, cell_offsets, w.redo, w.redo + 2 * N, w.mail};
     la.route = lattice_route();
     if (launch_lattice(stream, la, N, LOAD_SKEWED) != hipSuccess) return RNNT_STATUS_WARP_FAILED;
     GradArgs ga{ws2, nullptr, xn, yn, alphas, betas, ll, grads2 ? grads2 : ws2, costs, mismatch,

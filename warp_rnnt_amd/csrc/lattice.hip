@@ -489,7 +489,8 @@ hipError_t launch_lattice(hipStream_t stream, const LatticeArgs& a, int N, int l
         // RNNT_LATTICE=logdomain|pd only provides its initial value): ROUTE_LOGDOMAIN pins the reference's
         // arithmetic, ROUTE_PD takes the probability-domain kernel wherever it is supported.
         const int nA = (a.U + WAVE - 1) / WAVE;
-        const bool pd_ok = a.redo && a.queue && !is_compact(a) && pd_shape_supported(a.T, a.U);
+        // (compact layout: the native entry's 64-bit cell offsets; a.T / a.U are then the launch bounds Tmax / Umax)
+        const bool pd_ok = a.redo && a.queue && !a.offs32 && pd_shape_supported(a.T, a.U);
         bool use_pd = pd_ok && (long long)2 * N * nA <= 256 && a.T >= 640 && a.T >= 2 * a.U;
         if (a.route == ROUTE_LOGDOMAIN) use_pd = false;
         if (a.route == ROUTE_PD) use_pd = pd_ok;

@@ -164,7 +164,7 @@ def loss_compact(xs, ys, xn, yn, blank=0, fastemit_lambda=0.0, required_grad=Tru
             raise RuntimeError("ys shape must be equal to (sum(yn), )")
         if STU != stu_chk:
             raise RuntimeError("xs shape mismatch with (\\sum{xn*(yn+1)}, )")
-        ws_bytes = L.rnnt_amd_workspace_size_compact(N, STU)
+        ws_bytes = L.rnnt_amd_workspace_size_compact(N, STU, tmax, umax)
         if ws_bytes == 0:
             raise RuntimeError("rnnt_loss status 5 (RNNT_STATUS_INVALID_ARGUMENT): unsupported sizes")
         ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
