@@ -131,6 +131,59 @@ def cpu_baseline(cfg, utts):
                       f"(log_softmax + gather + loss + grads), {dt:.2f} s wall, OpenMP over rows/utterances"}
 
 
+def gather_roofline(lp, ys, N, T, U, V, reps):
+    """The gather kernel of the loss entry alone (k_to_diagonal<true>: dense log-probs -> diagonal-major pairs),
+    HIP events on the launch stream.  Two prices: the ALGORITHMIC bytes of SURVEY.md 8(d) (16 B per cell: 8 read, 8
+    written) and the bytes of the 128-byte lines those reads live in -- the memory system fetches whole lines (a
+    one-dword-per-line probe over the same tensor takes as long as reading all of it,
+    profiles/r03_ubench_gather_variants.txt), so the second is the floor of this access pattern on this part."""
+    import numpy as np
+    from warp_rnnt_amd import _lib
+    L = _lib.load()
+    dev = lp.device
+    ws = torch.empty((L.rnnt_amd_workspace_size(N, T, U),), dtype=torch.uint8, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def call():
+        st = L.rnnt_amd_debug_gather_only(stream, ws.data_ptr(), lp.data_ptr(), ys.data_ptr(), N, T, U, V, 0)
+        assert st == 0
+    call()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(reps):
+        call()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    cells = N * T * U
+    alg = 16.0 * cells
+    out = {"bound": "hbm", "kernel": "k_to_diagonal<true> (dense log-probs -> diagonal-major (blank,label) pairs)",
+           "achieved": round(alg / (ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+           "frac": round(alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "algorithmic_bytes": alg,
+           "kernel_ms": round(ms, 4), "traffic": None}
+    if cells <= 8_000_000:
+        # distinct 128-byte lines that hold a blank or a label log-prob of some cell (exact, on the host)
+        lab = np.zeros((N, U), dtype=np.int64)
+        lab[:, :U - 1] = ys.cpu().numpy()
+        row = np.arange(cells, dtype=np.int64).reshape(N, T, U) * (V * 4)
+        lines = np.unique(np.concatenate([(row // 128).ravel(), ((row + lab[:, None, :] * 4) // 128).ravel()])).size
+        line_bytes = lines * 128.0 + 8.0 * cells
+        out["line_bytes"] = line_bytes
+        out["line_rate"] = round(line_bytes / (ms * 1e-3) / 1e9, 1)
+        out["line_frac"] = round(line_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+    try:
+        with open(os.path.join(ROOT, "profiles", "hbm_traffic.json")) as f:
+            rec = json.load(f).get("c4_gather") if (N, T, U, V) == (16, 1500, 300, 50) else None
+            if rec:
+                out["traffic"] = rec["traffic_bytes"]
+                out["traffic_source"] = ("profiles/hbm_traffic.json: " + rec["source"] +
+                                         " (a committed measurement, not taken in this run)")
+    except OSError:
+        pass
+    return out
+
+
 def self_launch(a):
     """`python bench.py --gpus N` with no launcher around it: re-execute under torch.distributed.run, one
     rank per GPU of this node, rendezvous on 127.0.0.1 (the container hostname may not resolve)."""
@@ -335,6 +388,8 @@ def main():
         torch.cuda.synchronize()
         extras["loss_only_ms"] = round(e0.elapsed_time(e1) / reps, 4)
         extras["fused_from_logits_ms"] = round(e1.elapsed_time(e2) / reps, 4)
+        if gather:
+            extras["roofline_gather"] = gather_roofline(lp, ys, N, T, U, V, reps)
         del lp
         # full training step (forward + backward to d/d logits), reference-style chain vs fused entry
         from warp_rnnt_amd.fused import rnnt_loss_from_logits

@@ -224,6 +224,11 @@ rnntStatus_t rnnt_amd_gather(rnntStream_t stream, const float *log_probs, const 
 rnntStatus_t rnnt_amd_debug_lattice_only(rnntStream_t stream, void *workspace, const int *xn,
                                          const int *yn, int N, int T, int U);
 
+/* Diagnostics (bench.py's roofline entry of the gather kernel): only the first step of
+ * rnnt_amd_loss(RNNT_IN_LOG_PROBS_DENSE) -- dense log-probs -> diagonal-major (blank,label) pairs in `workspace`. */
+rnntStatus_t rnnt_amd_debug_gather_only(rnntStream_t stream, void *workspace, const float *log_probs,
+                                        const int *labels, int N, int T, int U, int V, int blank);
+
 /* Diagnostics (tests/pd_vs_oracle.py): byte offset, inside the workspace, of the (2N,) int32 flags the
  * probability-domain lattice kernel leaves for the log-domain kernel launched behind it: flags[2n+dir] != 0 means
  * sweep `dir` (0 alpha, 1 beta) of utterance n was redone in the log domain (bit 0: an input outside the range

@@ -3,7 +3,7 @@
 # Copy the summaries into profiles/ afterwards with `python tools/summarise_profiles.py $TAG`.
 #   --pmc passes are separate from each other and never combined with other trace domains.
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
@@ -22,14 +22,25 @@ rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch_
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write_c3 -o c3 -- python $R/bench.py --config c3 --steps 10 --warmup 2 --no-cpu-baseline > /dev/null 2>&1
 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU --kernel-trace --output-format csv -d $OUT/pmc_sq1 -o c4 -- python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline > /dev/null 2>&1
 rocprofv3 --pmc SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_SCA --kernel-trace --output-format csv -d $OUT/pmc_sq2 -o c4 -- python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline > /dev/null 2>&1
+# gather path: TA / TCP / TCC counters of the loss entry's kernels (tools/gather_probe.py = rnnt_amd_loss on dense log-probs)
+i=0
+for set in "TA_BUSY_avr TA_TA_BUSY_sum TCP_TA_TCP_STATE_READ_sum" "GRBM_GUI_ACTIVE TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum" \
+           "TCC_REQ_sum TCC_HIT_sum TCC_MISS_sum" "TCC_TAG_STALL_sum TCC_EA0_RDREQ_DRAM_sum TCC_BUSY_avr" \
+           "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum" "FETCH_SIZE" "WRITE_SIZE"; do
+  i=$((i+1))
+  rocprofv3 --pmc $set --kernel-trace --output-format csv -d $OUT/pmc_gather$i -o g -- python $R/tools/gather_probe.py $R/warp_rnnt_amd/libwarp_rnnt_amd.so > /dev/null 2>&1
+done
+# what FETCH_SIZE tallies per touched 128-byte line (one dword per 64 / 128 / 256 / 512 bytes over 1.44 GB)
+PROBES_ONLY=1 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_probe -o p -- $R/tools/ubench/gather_variants > /dev/null 2>&1
+$R/tools/ubench/gather_variants > $OUT/ubench_gather_variants.txt 2>&1
 cd $R
 # parity at BASELINE sizes: the shipped build, the same with the log-domain lattice kernels only, and the libm build
 rm -f $OUT/parity_errors.json
-RNNT_PARITY_TABLE=$OUT/parity_errors.json RNNT_PARITY_BUILD="default (probability-domain lattice for c4/c5)" python -m pytest tests/test_gpu_baseline_sizes.py -q > $OUT/parity_default.log 2>&1
-RNNT_LATTICE=logdomain RNNT_PARITY_TABLE=$OUT/parity_errors.json RNNT_PARITY_BUILD="log-domain lattice, hardware exp2/log2 lse (RNNT_LATTICE=logdomain)" python -m pytest tests/test_gpu_baseline_sizes.py -q > $OUT/parity_logdomain.log 2>&1
-WARP_RNNT_AMD_LIB=$R/warp_rnnt_amd/libwarp_rnnt_amd_precise.so RNNT_PARITY_TABLE=$OUT/parity_errors.json RNNT_PARITY_BUILD="log-domain lattice, libm expf/log1pf (-DRNNT_PRECISE_LIBM)" python -m pytest tests/test_gpu_baseline_sizes.py -q > $OUT/parity_precise.log 2>&1
+# (the test file runs every configuration on both lattice routes itself since round 3: rows carry "route")
+RNNT_PARITY_TABLE=$OUT/parity_errors.json RNNT_PARITY_BUILD="shipped" python -m pytest tests/test_gpu_baseline_sizes.py -q > $OUT/parity_default.log 2>&1
+WARP_RNNT_AMD_LIB=$R/warp_rnnt_amd/libwarp_rnnt_amd_precise.so RNNT_PARITY_TABLE=$OUT/parity_errors.json RNNT_PARITY_BUILD="log-domain lattice, libm expf/log1pf (-DRNNT_PRECISE_LIBM)" python -m pytest tests/test_gpu_baseline_sizes.py -q -k "logdomain and not full_per_rank" > $OUT/parity_precise.log 2>&1
 # lattice kernel alone, both arithmetic domains
-for sh in 16,1500,300 16,1500,64 16,1500,128 16,1500,512 8,3000,500 32,1500,300 64,1500,300 16,700,100 16,400,100 16,150,40; do
+for sh in 16,1500,300 16,1500,64 16,1500,128 16,1500,512 8,3000,500 24,1500,300 32,1500,300 64,1500,300 16,700,100 16,400,100 16,150,40; do
   for v in pd logdomain; do
     RNNT_LATTICE=$v python tools/lattice_probe.py --shape $sh main: 2>&1 | grep median | sed "s/^main */N,T,U=$sh lattice=$v  /"
   done
@@ -38,7 +49,8 @@ done > $OUT/lattice_probe.txt
 tools/ubench/pd_steps > $OUT/ubench_pd_steps.txt 2>&1
 python tools/host_overhead.py 2>&1 | grep -v amdgpu > $OUT/host_overhead.txt
 (echo "== ctypes fallback"; WARP_RNNT_AMD_NO_NATIVE_BINDING=1 python tools/host_overhead.py 2>&1 | grep -v amdgpu) >> $OUT/host_overhead.txt
-for l in warp-rnnt-gather warp-rnnt-fused; do
+python $R/bench.py --no-cpu-baseline --rccl-group > $OUT/bench_c4_rccl_group.json 2>> $OUT/bench.err
+for l in warp-rnnt-gather warp-rnnt-fused warp-rnnt-compact; do
   timeout 200 python $R/tools/benchmark_table.py --loss $l --markdown $OUT/table_$l.md > $OUT/table_$l.log 2>&1
 done
 ls $OUT

@@ -10,7 +10,7 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-TAG = sys.argv[1] if len(sys.argv) > 1 else "r02"
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r03"
 SRC = os.path.join(ROOT, "gpurun_out", TAG)
 DST = os.path.join(ROOT, "profiles")
 
@@ -45,11 +45,26 @@ def main():
     agg = pmc_summary(["pmc_fetch", "pmc_write"], os.path.join(DST, f"{TAG}_rocprof_c4_pmc_hbm.csv"))
     pmc_summary(["pmc_sq1", "pmc_sq2"], os.path.join(DST, f"{TAG}_rocprof_c4_pmc_sq.csv"))
     if glob.glob(os.path.join(SRC, "pmc_gather1", "*_counter_collection.csv")):
-        pmc_summary([f"pmc_gather{i}" for i in range(1, 6)], os.path.join(DST, f"{TAG}_rocprof_c4_pmc_gather_path.csv"))
+        gagg = pmc_summary([f"pmc_gather{i}" for i in range(1, 8)], os.path.join(DST, f"{TAG}_rocprof_c4_pmc_gather_path.csv"))
+    else:
+        gagg = {}
+    # calibration of FETCH_SIZE on a known access pattern: one dword per STRIDE bytes over the c4 tensor
+    pagg = collections.defaultdict(list)
+    for f in glob.glob(os.path.join(SRC, "pmc_probe", "*_counter_collection.csv")):
+        for r in csv.DictReader(open(f)):
+            if "k_probe" in r["Kernel_Name"] and r["Counter_Name"] == "FETCH_SIZE":
+                pagg[(r["Kernel_Name"].split("(")[0].replace("void ", ""), r.get("Grid_Size", ""))].append(float(r["Counter_Value"]))
+    if pagg:
+        with open(os.path.join(DST, f"{TAG}_rocprof_probe_fetch_size.csv"), "w", newline="") as fh:
+            w = csv.writer(fh)
+            w.writerow(["kernel", "grid_size", "dispatches", "mean_FETCH_SIZE_KiB"])
+            for (k, g), v in sorted(pagg.items()):
+                w.writerow([k, g, len(v), round(sum(v) / len(v), 1)])
     for f in glob.glob(os.path.join(SRC, "table_*.md")):
         shutil.copy(f, os.path.join(DST, f"{TAG}_" + os.path.basename(f)))
     for name in ("parity_errors.json", "lattice_probe.txt", "ubench_pd_steps.txt", "host_overhead.txt",
-                 "bench_c4_logdomain_lattice.json", "graph_probe.txt"):
+                 "bench_c4_logdomain_lattice.json", "bench_c4_rccl_group.json", "graph_probe.txt",
+                 "ubench_gather_variants.txt"):
         if os.path.exists(os.path.join(SRC, name)):
             shutil.copy(os.path.join(SRC, name), os.path.join(DST, f"{TAG}_" + name))
     # HBM traffic of the dominant kernel, per launch (FETCH_SIZE doubled for wide coalesced reads)
@@ -67,6 +82,18 @@ def main():
                         "traffic_bytes": f_kib * 2048 + w_kib * 1024,
                         "source": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/collect_profiles.sh {TAG} "
                                   f"(profiles/{TAG}_rocprof_{cfg}_pmc_hbm.csv)"}
+    # the gather kernel of the loss entry (sparse dword reads: the counter tallies 64 B per request while the memory
+    # system moves the whole 128-byte line -- profiles/<tag>_rocprof_probe_fetch_size.csv, the stride probes of
+    # tools/ubench/gather_variants.hip run as long as a full read -- so FETCH_SIZE is doubled here too)
+    def gpick(counter):
+        ks = [k for k in gagg if "k_to_diagonal<true>" in k[0].replace(" ", "") and k[1] == counter]
+        return sum(gagg[ks[0]]) / len(gagg[ks[0]]) if ks else None
+    gf, gw = gpick("FETCH_SIZE"), gpick("WRITE_SIZE")
+    if gf is not None and gw is not None:
+        doc["c4_gather"] = {"kernel": "rnnt::k_to_diagonal<true>", "fetch_size_kib": gf, "write_size_kib": gw,
+                            "traffic_bytes": gf * 2048 + gw * 1024,
+                            "source": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over tools/gather_probe.py, "
+                                      f"tools/collect_profiles.sh {TAG} (profiles/{TAG}_rocprof_c4_pmc_gather_path.csv)"}
     json.dump(doc, open(os.path.join(DST, "hbm_traffic.json"), "w"), indent=1)
     # bench.py reads hbm_traffic.json at run time, i.e. the file of the PREVIOUS collection; fill a missing
     # `roofline.traffic` from the PMC passes of this same collection

@@ -324,7 +324,9 @@ int main(int argc, char** argv) {
     }
     printf("N=%d T=%d U=%d V=%d: dense %.3f GB, pairs %.4f GB\n", N, T, U, V, bytes / 1e9, cells * 8 / 1e9);
 
-    // ---- probes
+    // ---- probes (PROBES_ONLY=1: nothing else -- the rocprofv3 --pmc FETCH_SIZE calibration pass of
+    //      tools/collect_profiles.sh: how many bytes does the counter tally per touched line?)
+    const bool probes_only = getenv("PROBES_ONLY") != nullptr;
     for (int stride : {64, 128, 256, 512}) {
         const size_t nline = bytes / stride;
         char name[128];
@@ -337,6 +339,7 @@ int main(int argc, char** argv) {
 #undef PROBE
     }
 
+    if (probes_only) return 0;
     // ---- variants
     const double useful = cells * 16 / 1e9;
     auto check = [&](const char* name) {

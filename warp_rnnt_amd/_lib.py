@@ -45,6 +45,7 @@ SYMBOLS = {
     "rnnt_amd_compact_scatter_grads": (_i, [_vp] * 6 + [_i64, _i, _i, _i]),
     "rnnt_amd_compact_offsets": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp]),
     "rnnt_amd_debug_lattice_only": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i]),
+    "rnnt_amd_debug_gather_only": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i]),
     "rnnt_amd_set_lattice": (_i, [_i]),
     "rnnt_amd_get_lattice": (_i, []),
     "rnnt_amd_version": (_i, []),

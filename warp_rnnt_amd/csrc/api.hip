@@ -209,6 +209,19 @@ bool compact_dims_ok(int N, int64_t STU, int Tmax, int Umax) {
 }
 }  // namespace
 
+// Diagnostics (bench.py: the gather kernel's own roofline entry): only step 1 of rnnt_amd_loss for dense log-probs,
+// i.e. k_to_diagonal<true> into the workspace's pair plane.
+rnntStatus_t rnnt_amd_debug_gather_only(rnntStream_t stream, void* workspace, const float* log_probs,
+                                        const int* labels, int N, int T, int U, int V, int blank) {
+    if (!dims_ok(N, T, U) || !workspace || V < 1 || blank < 0 || blank >= V) return RNNT_STATUS_INVALID_ARGUMENT;
+    if (U > 1 && !labels) return RNNT_STATUS_INVALID_ARGUMENT;
+    Workspace w;
+    carve(workspace, N, T, U, &w);
+    if (launch_gather(stream, log_probs, labels, w.ws2, N, T, U, V, blank, true) != hipSuccess)
+        return RNNT_STATUS_PROLOGUE_FAILED;
+    return RNNT_STATUS_SUCCESS;
+}
+
 size_t rnnt_amd_workspace_size_compact(int N, int64_t STU, int Tmax, int Umax) {
     if (!compact_dims_ok(N, STU, Tmax, Umax)) return 0;
     return carve_compact(nullptr, N, STU, Tmax > 0 ? Tmax : 1, Umax > 0 ? Umax : 1, nullptr);

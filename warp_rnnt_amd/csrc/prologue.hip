@@ -754,8 +754,8 @@ k_gather_compact(const float* __restrict__ xs, const int* __restrict__ ys, const
         const int tl = tl0 + 8 * k, t = t0 + tl;
         if (t < T && u < U) {
             const size_t cell = nbase + (size_t)t * U + u;
-            const float* p = xs + cell * (size_t)V;
-            tile[tl][ul] = make_float2(p[blank], p[lab]);
+            const float* p = xs + cell * (size_t)V;      // (non-temporal: see k_to_diagonal)
+            tile[tl][ul] = make_float2(__builtin_nontemporal_load(p + blank), __builtin_nontemporal_load(p + lab));
             if (loc) loc[cell] = lab;
         }
     }
