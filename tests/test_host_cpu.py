@@ -43,6 +43,52 @@ def test_header_symbols_exported():
         assert re.search(r"\bT " + name + r"\b", syms), name
 
 
+def test_lattice_route_is_a_runtime_setting_and_sizes_do_not_depend_on_it():
+    """rnnt_amd_set_lattice / warp_rnnt_amd.set_lattice: host-side state only (one atomic), so it is testable here.
+    The workspace size is a function of the shape alone -- a caller may size, change the route, then call."""
+    import warp_rnnt_amd
+    L = warp_rnnt_amd.load()
+    start = warp_rnnt_amd.get_lattice()
+    try:
+        assert start in warp_rnnt_amd.LATTICE_ROUTES
+        sizes = {}
+        for route in ("logdomain", "pd", "auto"):
+            prev = warp_rnnt_amd.set_lattice(route)
+            assert prev in warp_rnnt_amd.LATTICE_ROUTES and warp_rnnt_amd.get_lattice() == route
+            sizes[route] = (L.rnnt_amd_workspace_size(16, 1500, 300), L.rnnt_amd_workspace_size(4, 150, 40),
+                            L.rnnt_amd_workspace_size_compact(16, 16 * 1500 * 300, 1500, 300))
+        assert sizes["logdomain"] == sizes["pd"] == sizes["auto"]
+        with warp_rnnt_amd.lattice_route("logdomain"):
+            assert warp_rnnt_amd.get_lattice() == "logdomain"
+            with warp_rnnt_amd.lattice_route("pd"):
+                assert warp_rnnt_amd.get_lattice() == "pd"
+            assert warp_rnnt_amd.get_lattice() == "logdomain"
+        assert warp_rnnt_amd.get_lattice() == "auto"
+        with pytest.raises(ValueError, match="unknown lattice route"):
+            warp_rnnt_amd.set_lattice("fast")
+        assert L.rnnt_amd_set_lattice(7) == -1 and warp_rnnt_amd.get_lattice() == "auto"   # unknown value: no change
+    finally:
+        warp_rnnt_amd.set_lattice(start)
+    # hand-over rings are reserved for shapes the probability-domain kernel can take (more than one column block,
+    # U <= 512) and for no others
+    cells = lambda n, t, u: n * t * u * 16
+    assert L.rnnt_amd_workspace_size(16, 1500, 64) - cells(16, 1500, 64) < 1 << 16
+    assert L.rnnt_amd_workspace_size(16, 1500, 300) - cells(16, 1500, 300) > 1 << 20
+    assert L.rnnt_amd_workspace_size(2, 100, 1100) - cells(2, 100, 1100) < 1 << 16
+    assert L.rnnt_amd_workspace_size_compact(4, 4 * 700 * 200, 700, 200) > L.rnnt_amd_workspace_size_compact(4, 4 * 700 * 200, 700, 64)
+
+
+def test_route_initial_value_comes_from_the_environment():
+    code = ("import sys; sys.path.insert(0, %r); import torch, warp_rnnt_amd; print(warp_rnnt_amd.get_lattice())" % ROOT)
+    for env, want in (({}, "auto"), ({"RNNT_LATTICE": "logdomain"}, "logdomain"), ({"RNNT_LATTICE": "pd"}, "pd")):
+        e = {k: v for k, v in os.environ.items() if k != "RNNT_LATTICE"}
+        e.update(env)
+        out = subprocess.run([sys.executable, "-c", code], env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                             timeout=300)
+        assert out.returncode == 0, out.stderr.decode()[-2000:]
+        assert out.stdout.decode().split()[-1] == want
+
+
 def test_missing_library_fails_loudly(monkeypatch):
     from warp_rnnt_amd import _lib
     monkeypatch.setattr(_lib, "_lib", None)
