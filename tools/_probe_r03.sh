@@ -1,11 +1,8 @@
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/r03
-(echo "== RNNT_LATTICE=pd --seconds 120 --seed 61"; RNNT_LATTICE=pd timeout 300 python tools/fuzz_parity.py --seconds 120 --seed 61 2>&1 | tail -3
-echo "== RNNT_LATTICE=pd --seconds 60 --seed 62 --big 0.3"; RNNT_LATTICE=pd timeout 300 python tools/fuzz_parity.py --seconds 60 --seed 62 --big 0.3 2>&1 | tail -3
-echo "== default routing --seconds 90 --seed 63"; timeout 300 python tools/fuzz_parity.py --seconds 90 --seed 63 2>&1 | tail -3) > gpurun_out/r03/fuzz1.txt
-cat gpurun_out/r03/fuzz1.txt
-python bench.py --no-cpu-baseline > gpurun_out/r03/bench3.json; python - <<'PY'
-import json
-d=json.loads(open('gpurun_out/r03/bench3.json').read().splitlines()[0])
-print(d['ms_per_step'], d['roofline']['kernel_ms'], d['roofline_loss_path']['kernels_ms'], d.get('roofline_gather'))
-PY
+for rep in 1 2 3; do
+for v in "" _gather_reverse; do
+  WARP_RNNT_AMD_LIB=$GRAFT_REPO_ROOT/warp_rnnt_amd/libwarp_rnnt_amd$v.so python bench.py --no-cpu-baseline --steps 100 2>/dev/null | python -c "
+import sys,json
+d=json.loads(sys.stdin.read().splitlines()[0]); print('lib$v', d['ms_per_step'], 'lsm', d['roofline']['kernel_ms'], 'loss', d['roofline_loss_path']['kernels_ms'], 'gather-alone', d['roofline_gather']['kernel_ms'])"
+done
+done

@@ -621,8 +621,14 @@ hipError_t launch_log_softmax_backward(hipStream_t stream, const float* dy, cons
 // write amplification: rocprofv3 WRITE_SIZE 268 MB for a 57.6 MB output.)
 // ---------------------------------------------------------------------------
 constexpr int TD = 32;   // tile edge
+// Tiles are walked from the END of the tensor to its beginning: in the caller's step the kernel in front of this one
+// is the log-softmax that has just written these log-probs front to back, and the last ~130-190 MB of what a
+// streaming kernel wrote are still in the 256 MB Infinity Cache (tools/ubench/mall_probe.hip: 128 MB read back from
+// the end of a freshly written 1.44 GB tensor in 22 us, from its beginning in 33-45 us).  Worth 8 us of the c4 step
+// (0.4237 -> 0.4157 ms for the loss entry inside bench.py, three interleaved runs each); nothing on a tensor that
+// was not just written (252 vs 249 us alone) -- which is how round 1 measured it and found no change.
 #ifndef RNNT_GATHER_REVERSE
-#define RNNT_GATHER_REVERSE 0
+#define RNNT_GATHER_REVERSE 1
 #endif
 
 #ifndef RNNT_GATHER_TT
@@ -635,9 +641,7 @@ __global__ void __launch_bounds__(256)
 k_to_diagonal(const float* __restrict__ src, const int* __restrict__ labels, float2* __restrict__ ws2,
               int T, int U, int V, int blank, int tiles_t, int tiles_u) {
     __shared__ float2 tile[TT][TD];
-    // (probe knob: walking the tensor back to front to catch the producer's tail in L2/MALL
-    //  measured no gain at 1.44 GB)
-    unsigned b = RNNT_GATHER_REVERSE ? gridDim.x - 1 - blockIdx.x : blockIdx.x;
+    unsigned b = (DENSE && RNNT_GATHER_REVERSE) ? gridDim.x - 1 - blockIdx.x : blockIdx.x;
     const int tu = b % tiles_u; b /= tiles_u;
     const int tt = b % tiles_t;
     const int n = b / tiles_t;
