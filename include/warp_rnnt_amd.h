@@ -8,7 +8,7 @@
  * read once per call), a launch counter per process and one per device (they
  * only make the hand-over tags of the probability-domain lattice kernel unique
  * per launch and per graph replay), a few A/B knobs read once from the
- * environment (RNNT_LSM_NO_WP, RNNT_LSMBWD_SMALLEST_COVER), a per-thread status
+ * environment (RNNT_LSM_NO_REGS, RNNT_LSM_NO_WP, RNNT_LSMBWD_SMALLEST_COVER), a per-thread status
  * for the void-returning compact entry points (rnnt_amd_compact_last_status)
  * and a once-per-process kernel attribute.  Nothing depends on what an earlier
  * call left in a workspace: scratch contents are unspecified on entry and exit.

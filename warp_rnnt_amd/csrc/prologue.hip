@@ -368,6 +368,108 @@ k_lsm_generic(const float* x, float* out, const int* __restrict__ labels,
     }
 }
 
+// ---------------------------------------------------------------------------
+// Small vocabularies, plain log-softmax, rows in REGISTERS (round 3).  KR whole rows (KR <= 4, KR*V a multiple of 4,
+// KR*V/4 <= 32 float4) form a 16-byte aligned group; a wave holds one group in lanes 0.. of each 32-lane half, one
+// float4 per lane (V = 50: two rows = 25 lanes of 32 busy, the 800 bytes of a wave's two groups contiguous), and
+// reduces the row maxima and sums with DPP butterflies inside the half (quad_perm xor 1 / xor 2, row_ror 4 / 8) plus
+// one ds_swizzle across its two DPP rows -- no LDS memory, no barrier, one float4 load and one store per lane and
+// group, non-temporal both ways.  This is the shape of the fastest plain copy on the part, and it runs at that
+// copy's rate: 462 us for the c4 tensor (6.24 TB/s read + write) where the LDS-staged kernel below takes 498
+// (tools/ubench/lsm_regs.hip, profiles/r03_ubench_lsm_regs.txt; without the non-temporal hint 484).
+// ---------------------------------------------------------------------------
+typedef float lsm_f4 __attribute__((ext_vector_type(4)));
+template <int CTRL> __device__ __forceinline__ float lsm_dpp(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float lsm_swz16(float v) {   // lane ^ 16 inside each 32-lane half
+    return __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), 0x401F));
+}
+__device__ __forceinline__ float half_max32(float v) {
+    v = fmaxf(v, lsm_dpp<0xB1>(v)); v = fmaxf(v, lsm_dpp<0x4E>(v)); v = fmaxf(v, lsm_dpp<0x124>(v));
+    v = fmaxf(v, lsm_dpp<0x128>(v));
+    return fmaxf(v, lsm_swz16(v));
+}
+__device__ __forceinline__ float half_sum32(float v) {
+    v += lsm_dpp<0xB1>(v); v += lsm_dpp<0x4E>(v); v += lsm_dpp<0x124>(v); v += lsm_dpp<0x128>(v);
+    return v + lsm_swz16(v);
+}
+constexpr int RG_UN = 2;          // groups per half and wave, loads first (1: 500 us, 2: 462-484, 4: 482-498)
+
+// NT: bit 0 = non-temporal loads, bit 1 = non-temporal stores
+template <int KR, int NT>
+__global__ void __launch_bounds__(256) k_lsm_regs(const float* __restrict__ x, float* __restrict__ out,
+                                                  const int64_t ngroups, const int V) {
+    const int lane = threadIdx.x & 63, j = lane & 31, half = lane >> 5;
+    const int g4 = (KR * V) >> 2;                  // float4 per group
+    const bool act = j < g4;
+    const int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const lsm_f4* __restrict__ xin = reinterpret_cast<const lsm_f4*>(x);
+    lsm_f4* __restrict__ xout = reinterpret_cast<lsm_f4*>(out);
+    // the lane's four elements: the first `ns` of them belong to row r0 of the group, the rest to row r0 + 1
+    const int e0 = 4 * j;
+    const int r0 = e0 / V;
+    const int ns = min(4, (r0 + 1) * V - e0);
+    lsm_f4 v[RG_UN];
+#pragma unroll
+    for (int i = 0; i < RG_UN; ++i) {
+        const int64_t g = (w * RG_UN + i) * 2 + half;
+        const float ninf = -__builtin_inff();
+        v[i] = lsm_f4{ninf, ninf, ninf, ninf};
+        if (act && g < ngroups) v[i] = (NT & 1) ? __builtin_nontemporal_load(xin + g * g4 + j) : xin[g * g4 + j];
+    }
+#pragma unroll
+    for (int i = 0; i < RG_UN; ++i) {
+        const int64_t g = (w * RG_UN + i) * 2 + half;
+        const lsm_f4 t = v[i];
+        const float ninf = -__builtin_inff();
+        // maxima of the lane's two parts, then of every row of the group over the half
+        const float a0 = t.x, a1 = ns > 1 ? t.y : ninf, a2 = ns > 2 ? t.z : ninf, a3 = ns > 3 ? t.w : ninf;
+        const float b1 = ns > 1 ? ninf : t.y, b2 = ns > 2 ? ninf : t.z, b3 = ns > 3 ? ninf : t.w;
+        const float mf = fmaxf(fmaxf(a0, a1), fmaxf(a2, a3)), ms = fmaxf(b1, fmaxf(b2, b3));
+        float M[KR];
+#pragma unroll
+        for (int r = 0; r < KR; ++r)
+            M[r] = half_max32(act ? (r0 == r ? mf : (r0 + 1 == r ? ms : ninf)) : ninf);
+        float m_first = M[0], m_second = M[KR - 1];
+#pragma unroll
+        for (int r = 1; r < KR; ++r) m_first = r0 == r ? M[r] : m_first;
+#pragma unroll
+        for (int r = KR - 2; r >= 0; --r) m_second = r0 + 1 == r ? M[r] : m_second;
+        const float kf = m_first * LOG2E, ks = m_second * LOG2E;
+        const float e0x = __builtin_amdgcn_exp2f(__builtin_fmaf(t.x, LOG2E, -kf));
+        const float e1x = __builtin_amdgcn_exp2f(__builtin_fmaf(t.y, LOG2E, ns > 1 ? -kf : -ks));
+        const float e2x = __builtin_amdgcn_exp2f(__builtin_fmaf(t.z, LOG2E, ns > 2 ? -kf : -ks));
+        const float e3x = __builtin_amdgcn_exp2f(__builtin_fmaf(t.w, LOG2E, ns > 3 ? -kf : -ks));
+        const float sf = e0x + (ns > 1 ? e1x : 0.f) + (ns > 2 ? e2x : 0.f) + (ns > 3 ? e3x : 0.f);
+        const float ss = (ns > 1 ? 0.f : e1x) + (ns > 2 ? 0.f : e2x) + (ns > 3 ? 0.f : e3x);
+        float Lg[KR];
+#pragma unroll
+        for (int r = 0; r < KR; ++r) {
+            const float sr = half_sum32(act ? (r0 == r ? sf : (r0 + 1 == r ? ss : 0.f)) : 0.f);
+            Lg[r] = M[r] + __builtin_amdgcn_logf(sr) * LN2;
+        }
+        float l_first = Lg[0], l_second = Lg[KR - 1];
+#pragma unroll
+        for (int r = 1; r < KR; ++r) l_first = r0 == r ? Lg[r] : l_first;
+#pragma unroll
+        for (int r = KR - 2; r >= 0; --r) l_second = r0 + 1 == r ? Lg[r] : l_second;
+        const lsm_f4 res = lsm_f4{t.x - l_first, t.y - (ns > 1 ? l_first : l_second), t.z - (ns > 2 ? l_first : l_second),
+                                  t.w - (ns > 3 ? l_first : l_second)};
+        if (act && g < ngroups) { if (NT & 2) __builtin_nontemporal_store(res, xout + g * g4 + j); else xout[g * g4 + j] = res; }
+    }
+}
+
+// rows per group for k_lsm_regs, or 0 when the kernel does not fit V: the largest KR <= 4 with KR*V a multiple of 4 and
+// KR*V/4 <= 32 lanes, if it keeps at least 20 of the 32 lanes of a half busy
+static int lsm_regs_rows_per_group(int V) {
+    if (V < 4) return 0;
+    int best = 0;
+    for (int k = 1; k <= 4; ++k)
+        if ((k * V) % 4 == 0 && (k * V) / 4 <= 32) best = k;
+    return (best && (best * V) / 4 >= 20) ? best : 0;
+}
+
 template <int MODE>
 static hipError_t dispatch_lsm(hipStream_t stream, const float* x, float* out, const int* labels,
                                int64_t rows, int V, int T, int U, int blank, LsmBwd bw) {
@@ -375,6 +477,32 @@ static hipError_t dispatch_lsm(hipStream_t stream, const float* x, float* out, c
     if (rows <= 0) return hipSuccess;
     const bool aligned = (reinterpret_cast<uintptr_t>(x) % 16 == 0) &&
                          (GATHER || reinterpret_cast<uintptr_t>(out) % 16 == 0);
+    if constexpr (MODE == LSM_NORM) {
+        // rows in registers where the vocabulary allows it (RNNT_LSM_NO_REGS=1: the LDS-staged kernel, for A/B runs)
+        static const bool no_regs = getenv("RNNT_LSM_NO_REGS") != nullptr;
+        const int kr = (aligned && !no_regs) ? lsm_regs_rows_per_group(V) : 0;
+        if (kr && rows >= kr) {
+            const int64_t ngroups = rows / kr;
+            const int64_t per_wg = 4 * RG_UN * 2;               // 4 waves x RG_UN groups x 2 halves
+            const int64_t grid = (ngroups + per_wg - 1) / per_wg;
+            if (grid < ((int64_t)1 << 31)) {
+                static const int nt = [] { const char* v = getenv("RNNT_LSM_REGS_NT"); return v ? atoi(v) & 3 : 3; }();
+#define LSM_REGS(KR)                                                                                          \
+    case KR:                                                                                                  \
+        if (nt == 0) k_lsm_regs<KR, 0><<<(unsigned)grid, 256, 0, stream>>>(x, out, ngroups, V);               \
+        else if (nt == 1) k_lsm_regs<KR, 1><<<(unsigned)grid, 256, 0, stream>>>(x, out, ngroups, V);          \
+        else if (nt == 2) k_lsm_regs<KR, 2><<<(unsigned)grid, 256, 0, stream>>>(x, out, ngroups, V);          \
+        else k_lsm_regs<KR, 3><<<(unsigned)grid, 256, 0, stream>>>(x, out, ngroups, V);                       \
+        break;
+                switch (kr) { LSM_REGS(1) LSM_REGS(2) LSM_REGS(3) LSM_REGS(4) }
+#undef LSM_REGS
+                const hipError_t e = hipGetLastError();
+                const int64_t done = ngroups * kr;              // (a group boundary: 16-byte aligned)
+                if (e != hipSuccess || done == rows) return e;
+                return dispatch_lsm<MODE>(stream, x + done * V, out + done * V, labels, rows - done, V, T, U, blank, bw);
+            }
+        }
+    }
     if (aligned && V <= 1024) {
         int L = 1;
         while (L < 64 && L * 16 < V) L <<= 1;          // <= 16 columns per lane
