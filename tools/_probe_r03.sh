@@ -1,10 +1,11 @@
 cd $GRAFT_REPO_ROOT
-for rep in 1 2 3 4; do
-for v in old nt0 nt1 nt2 nt3; do
-  unset RNNT_LSM_NO_REGS RNNT_LSM_REGS_NT
-  case $v in old) export RNNT_LSM_NO_REGS=1;; nt0) export RNNT_LSM_REGS_NT=0;; nt1) export RNNT_LSM_REGS_NT=1;; nt2) export RNNT_LSM_REGS_NT=2;; nt3) export RNNT_LSM_REGS_NT=3;; esac
-  python bench.py --no-cpu-baseline --steps 200 2>/dev/null | python -c "
+timeout 600 python -m pytest tests/test_gpu_parity.py tests/test_gpu_wrapper.py -q -x 2>&1 | tail -5
+for rep in 1 2; do
+for v in new old; do
+  unset RNNT_LSM_NO_REGS
+  if [ $v = old ]; then export RNNT_LSM_NO_REGS=1; fi
+  python bench.py --no-cpu-baseline --steps 100 2>/dev/null | python -c "
 import sys,json
-d=json.loads(sys.stdin.read().splitlines()[0]); print('$v', d['ms_per_step'], 'lsm', d['roofline']['kernel_ms'], 'loss', d['roofline_loss_path']['kernels_ms'])"
+d=json.loads(sys.stdin.read().splitlines()[0]); print('$v', d['ms_per_step'], 'fused_fwd', d['fused_from_logits_ms'], 'train_fused', d['train_step_fused_logits_ms'], 'train_native_chain', d['train_step_native_log_softmax_chain_ms'])"
 done
 done

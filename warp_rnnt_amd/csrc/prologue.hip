@@ -443,19 +443,22 @@ __global__ void __launch_bounds__(256) k_lsm_regs(const float* __restrict__ x, f
         const float e3x = __builtin_amdgcn_exp2f(__builtin_fmaf(t.w, LOG2E, ns > 3 ? -kf : -ks));
         const float sf = e0x + (ns > 1 ? e1x : 0.f) + (ns > 2 ? e2x : 0.f) + (ns > 3 ? e3x : 0.f);
         const float ss = (ns > 1 ? 0.f : e1x) + (ns > 2 ? 0.f : e2x) + (ns > 3 ? 0.f : e3x);
+        // log-sum of every row; the result is (x - max) - log-sum, the association of the LDS-staged kernel (and of
+        // torch): subtracting a rounded max + log-sum instead loses an ulp of |max| per element, which the lattice
+        // amplifies to 1e-4 on the gradients at c2's size
         float Lg[KR];
 #pragma unroll
-        for (int r = 0; r < KR; ++r) {
-            const float sr = half_sum32(act ? (r0 == r ? sf : (r0 + 1 == r ? ss : 0.f)) : 0.f);
-            Lg[r] = M[r] + __builtin_amdgcn_logf(sr) * LN2;
-        }
+        for (int r = 0; r < KR; ++r)
+            Lg[r] = __builtin_amdgcn_logf(half_sum32(act ? (r0 == r ? sf : (r0 + 1 == r ? ss : 0.f)) : 0.f)) * LN2;
         float l_first = Lg[0], l_second = Lg[KR - 1];
 #pragma unroll
         for (int r = 1; r < KR; ++r) l_first = r0 == r ? Lg[r] : l_first;
 #pragma unroll
         for (int r = KR - 2; r >= 0; --r) l_second = r0 + 1 == r ? Lg[r] : l_second;
-        const lsm_f4 res = lsm_f4{t.x - l_first, t.y - (ns > 1 ? l_first : l_second), t.z - (ns > 2 ? l_first : l_second),
-                                  t.w - (ns > 3 ? l_first : l_second)};
+        const lsm_f4 res = lsm_f4{(t.x - m_first) - l_first,
+                                  ns > 1 ? (t.y - m_first) - l_first : (t.y - m_second) - l_second,
+                                  ns > 2 ? (t.z - m_first) - l_first : (t.z - m_second) - l_second,
+                                  ns > 3 ? (t.w - m_first) - l_first : (t.w - m_second) - l_second};
         if (act && g < ngroups) { if (NT & 2) __builtin_nontemporal_store(res, xout + g * g4 + j); else xout[g * g4 + j] = res; }
     }
 }
