@@ -24,6 +24,21 @@
 
 namespace rnnt {
 
+// cache policy of the dense-row writes (a pure writer of 4V bytes per cell): 1 = non-temporal stores (round 3: the
+// gather=True training step through the native log-softmax function 1.96 -> 1.90 ms at c4, profiles/r03_bwd_nt_ab.txt)
+#ifndef RNNT_EX_NT
+#define RNNT_EX_NT 1
+#endif
+typedef float ex_f4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void ex_store4(float4* p, float4 v) {
+    if (RNNT_EX_NT) {
+        const ex_f4 w = {v.x, v.y, v.z, v.w};
+        __builtin_nontemporal_store(w, reinterpret_cast<ex_f4*>(p));
+    } else {
+        *p = v;
+    }
+}
+
 struct ExpandCell {
     float gB, gL;   // scaled gradients of the blank and label slot
     int lab;        // vocabulary index of the label slot, or -1 when nothing goes there
@@ -113,7 +128,7 @@ k_expand_small(const Rows rows, float* __restrict__ dense, unsigned cells, int R
     __syncthreads();
     float* dst = dense + (size_t)cell0 * V;
     for (int i = tid; i < nvec; i += EX_THREADS)
-        reinterpret_cast<float4*>(dst)[i] = reinterpret_cast<const float4*>(tile)[i];
+        ex_store4(reinterpret_cast<float4*>(dst) + i, reinterpret_cast<const float4*>(tile)[i]);
     for (int e = (nvec << 2) + tid; e < nel; e += EX_THREADS) dst[e] = tile[e];
 }
 
@@ -131,7 +146,7 @@ k_expand_large(const Rows rows, float* __restrict__ dense, unsigned cells, int V
                 const int v = v0 + j;
                 o[j] = ((v == blank) ? c.gB : 0.0f) + ((v == c.lab) ? c.gL : 0.0f);
             }
-            if constexpr (VEC == 4) *reinterpret_cast<float4*>(dst + v0) = make_float4(o[0], o[1], o[2], o[3]);
+            if constexpr (VEC == 4) ex_store4(reinterpret_cast<float4*>(dst + v0), make_float4(o[0], o[1], o[2], o[3]));
             else dst[v0] = o[0];
         }
     }

@@ -72,22 +72,34 @@ __device__ __forceinline__ CellMap map_cell(size_t cell, const int* __restrict__
 //   v_exp_f32 unit, log(sum) as v_log_f32 * ln2 (sum in [1,V]); both are within
 //   ~2 ulp, the result is within 4e-6 of torch.log_softmax (tests).
 // ---------------------------------------------------------------------------
-#ifdef RNNT_LSM_NT
+// Cache policy of the LDS-staged kernel's 16-byte global loads and stores: non-temporal in the fused modes (gather:
+// a read-only stream of the logits; backward: logits in, d/d logits out -- fused forward 0.472 -> 0.464 ms, fused
+// training step 1.00 -> 0.975 ms at c4, profiles/r03_bwd_nt_ab.txt), plain for the log-softmax itself, where the
+// hints measured nothing to worse in rounds 1-2 (HISTORY.md).  -DRNNT_LSM_NT forces them everywhere (A/B builds).
 typedef float rnnt_f4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ float4 rnnt_nt_load(const float4* p) {
-    rnnt_f4 v = __builtin_nontemporal_load(reinterpret_cast<const rnnt_f4*>(p));
-    return make_float4(v.x, v.y, v.z, v.w);
+template <bool NT> __device__ __forceinline__ float4 lsm_load4(const float4* p) {
+    if constexpr (NT) {
+        const rnnt_f4 v = __builtin_nontemporal_load(reinterpret_cast<const rnnt_f4*>(p));
+        return make_float4(v.x, v.y, v.z, v.w);
+    } else {
+        return *p;
+    }
 }
-__device__ __forceinline__ void rnnt_nt_store(float4* p, float4 v) {
-    rnnt_f4 w = {v.x, v.y, v.z, v.w};
-    __builtin_nontemporal_store(w, reinterpret_cast<rnnt_f4*>(p));
+template <bool NT> __device__ __forceinline__ void lsm_store4(float4* p, float4 v) {
+    if constexpr (NT) {
+        const rnnt_f4 w = {v.x, v.y, v.z, v.w};
+        __builtin_nontemporal_store(w, reinterpret_cast<rnnt_f4*>(p));
+    } else {
+        *p = v;
+    }
 }
-#define RNNT_LSM_LOAD(p) rnnt_nt_load(p)
-#define RNNT_LSM_STORE(p, v) rnnt_nt_store(p, v)
+#ifdef RNNT_LSM_NT
+#define RNNT_LSM_NT_MODE(MODE) true
 #else
-#define RNNT_LSM_LOAD(p) (*(p))
-#define RNNT_LSM_STORE(p, v) (*(p) = (v))
+#define RNNT_LSM_NT_MODE(MODE) ((MODE) != LSM_NORM)
 #endif
+#define RNNT_LSM_LOAD(p) lsm_load4<RNNT_LSM_NT_MODE(MODE)>(p)
+#define RNNT_LSM_STORE(p, v) lsm_store4<RNNT_LSM_NT_MODE(MODE)>(p, v)
 
 // What the log-softmax kernels emit.
 enum LsmMode : int {
@@ -237,6 +249,25 @@ k_lsm_small(const float* x, float* out, const int* __restrict__ labels,
 // picks 1.25-2.5 float4 per thread for the plain log-softmax and the smallest cover for the read-mostly fused modes
 // (dispatch_lsm).
 constexpr int LG_MAXV = 16384;
+// cache policy of the plain (LSM_NORM) row-per-workgroup stream: bit 0 = non-temporal loads, bit 1 = non-temporal stores.
+// Both (round 3; round 1 had tried them on the LDS-staged small-V kernel only, where they do nothing): c5 (V=10000, in
+// place, 288 GB of traffic) 57.4 -> 51.3 ms per step, c3 (V=5000) 0.708 -> 0.695 ms; loads alone are WORSE (c3 0.733),
+// stores alone neutral (profiles/r03_lg_nt_ab.txt)
+#ifndef RNNT_LG_NT
+#define RNNT_LG_NT 3
+#endif
+#ifndef RNNT_LG_NT_FUSED      // the same policy in the fused gather / backward modes: c3 fused forward 0.336 -> 0.325 ms,
+#define RNNT_LG_NT_FUSED 1    // fused training step 1.051 -> 1.018 ms (profiles/r03_lg_fused_nt_ab.txt)
+#endif
+typedef float lg_f4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 rnnt_nt_load4(const float4* p) {
+    const lg_f4 v = __builtin_nontemporal_load(reinterpret_cast<const lg_f4*>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void rnnt_nt_store4(float4* p, float4 v) {
+    const lg_f4 w = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(w, reinterpret_cast<lg_f4*>(p));
+}
 
 template <int THREADS>
 __device__ __forceinline__ float block_reduce(float v, bool is_max, float* red) {
@@ -266,7 +297,7 @@ k_lsm_large(const float* x, float* out, const int* __restrict__ labels,
     for (int i = 0; i < LG_MAXVEC; ++i) {
         const int j = threadIdx.x + i * LG_THREADS;
         if (j < nvec) {
-            v[i] = src[j];
+            v[i] = (((MODE == LSM_NORM ? 1 : RNNT_LG_NT_FUSED) * RNNT_LG_NT) & 1) ? rnnt_nt_load4(src + j) : src[j];
             mx = fmaxf(fmaxf(mx, fmaxf(v[i].x, v[i].y)), fmaxf(v[i].z, v[i].w));
         }
     }
@@ -309,7 +340,8 @@ k_lsm_large(const float* x, float* out, const int* __restrict__ labels,
                     d += (e == m.label) ? gL : 0.0f;
                     o[cc] = d;
                 }
-                dst[j] = make_float4(o[0], o[1], o[2], o[3]);
+                if ((RNNT_LG_NT_FUSED * RNNT_LG_NT) & 2) rnnt_nt_store4(dst + j, make_float4(o[0], o[1], o[2], o[3]));
+                else dst[j] = make_float4(o[0], o[1], o[2], o[3]);
             }
         }
     } else {
@@ -317,9 +349,11 @@ k_lsm_large(const float* x, float* out, const int* __restrict__ labels,
 #pragma unroll
         for (int i = 0; i < LG_MAXVEC; ++i) {
             const int j = threadIdx.x + i * LG_THREADS;
-            if (j < nvec)
-                dst[j] = make_float4((v[i].x - mx) - ls, (v[i].y - mx) - ls, (v[i].z - mx) - ls,
-                                     (v[i].w - mx) - ls);
+            if (j < nvec) {
+                const float4 r = make_float4((v[i].x - mx) - ls, (v[i].y - mx) - ls, (v[i].z - mx) - ls,
+                                             (v[i].w - mx) - ls);
+                if (RNNT_LG_NT & 2) rnnt_nt_store4(dst + j, r); else dst[j] = r;
+            }
         }
     }
     }
@@ -607,6 +641,15 @@ hipError_t launch_logits_backward(hipStream_t stream, const float* logits, const
 }
 
 // ---------------------------------------------------------------------------
+// cache policy of the log-softmax backward streams: bit 0 = non-temporal loads (dy, y), bit 1 = non-temporal stores (dx)
+// Both (round 3): the reference's call chain with the native log-softmax autograd function 1.96 -> 1.89 ms per training
+// step at c4 (with the expand kernel's non-temporal stores on top: 1.84), profiles/r03_bwd_nt_ab.txt.
+#ifndef RNNT_LSMB_NT
+#define RNNT_LSMB_NT 3
+#endif
+#define LSMB_LD(p) ((RNNT_LSMB_NT & 1) ? rnnt_nt_load4(p) : *(p))
+#define LSMB_ST(p, v) do { if (RNNT_LSMB_NT & 2) rnnt_nt_store4((p), (v)); else *(p) = (v); } while (0)
+
 // Backward of log-softmax: dx = dy - exp(y) * sum_v(dy), y = the log-probabilities.
 // Same three shapes as the forward kernels (LDS row tiles / one row per workgroup in
 // registers / wave per row); 12V bytes per row element (read dy, read y, write dx).
@@ -626,8 +669,8 @@ k_lsmbwd_small(const float* dy, const float* y, float* dx, int64_t rows, int V, 
     const float* sdy = dy + row0 * V;
     const float* sy = y + row0 * V;
     for (int i = tid; i < nvec; i += SMB_THREADS) {
-        reinterpret_cast<float4*>(tdy)[i] = reinterpret_cast<const float4*>(sdy)[i];
-        reinterpret_cast<float4*>(ty)[i] = reinterpret_cast<const float4*>(sy)[i];
+        reinterpret_cast<float4*>(tdy)[i] = LSMB_LD(reinterpret_cast<const float4*>(sdy) + i);
+        reinterpret_cast<float4*>(ty)[i] = LSMB_LD(reinterpret_cast<const float4*>(sy) + i);
     }
     for (int e = (nvec << 2) + tid; e < nel; e += SMB_THREADS) { tdy[e] = sdy[e]; ty[e] = sy[e]; }
     __syncthreads();
@@ -649,7 +692,7 @@ k_lsmbwd_small(const float* dy, const float* y, float* dx, int64_t rows, int V, 
     __syncthreads();
     float* dst = dx + row0 * V;
     for (int i = tid; i < nvec; i += SMB_THREADS)
-        reinterpret_cast<float4*>(dst)[i] = reinterpret_cast<const float4*>(tdy)[i];
+        LSMB_ST(reinterpret_cast<float4*>(dst) + i, reinterpret_cast<const float4*>(tdy)[i]);
     for (int e = (nvec << 2) + tid; e < nel; e += SMB_THREADS) dst[e] = tdy[e];
 }
 
@@ -666,7 +709,7 @@ k_lsmbwd_large(const float* dy, const float* y, float* dx, int64_t rows, int V) 
 #pragma unroll
         for (int i = 0; i < LG_MAXVEC; ++i) {
             const int j = threadIdx.x + i * LG_THREADS;
-            if (j < nvec) { g[i] = sdy[j]; s += (g[i].x + g[i].y) + (g[i].z + g[i].w); }
+            if (j < nvec) { g[i] = LSMB_LD(sdy + j); s += (g[i].x + g[i].y) + (g[i].z + g[i].w); }
         }
         s = block_reduce<LG_THREADS>(s, false, red);
         float4* dst = reinterpret_cast<float4*>(dx + row * V);
@@ -674,11 +717,11 @@ k_lsmbwd_large(const float* dy, const float* y, float* dx, int64_t rows, int V) 
         for (int i = 0; i < LG_MAXVEC; ++i) {
             const int j = threadIdx.x + i * LG_THREADS;
             if (j < nvec) {
-                const float4 p = sy[j];
-                dst[j] = make_float4(__builtin_fmaf(-__builtin_amdgcn_exp2f(p.x * LOG2E), s, g[i].x),
-                                     __builtin_fmaf(-__builtin_amdgcn_exp2f(p.y * LOG2E), s, g[i].y),
-                                     __builtin_fmaf(-__builtin_amdgcn_exp2f(p.z * LOG2E), s, g[i].z),
-                                     __builtin_fmaf(-__builtin_amdgcn_exp2f(p.w * LOG2E), s, g[i].w));
+                const float4 p = LSMB_LD(sy + j);
+                LSMB_ST(dst + j, make_float4(__builtin_fmaf(-__builtin_amdgcn_exp2f(p.x * LOG2E), s, g[i].x),
+                                             __builtin_fmaf(-__builtin_amdgcn_exp2f(p.y * LOG2E), s, g[i].y),
+                                             __builtin_fmaf(-__builtin_amdgcn_exp2f(p.z * LOG2E), s, g[i].z),
+                                             __builtin_fmaf(-__builtin_amdgcn_exp2f(p.w * LOG2E), s, g[i].w)));
             }
         }
     }
