@@ -447,7 +447,7 @@ def main():
                        "baseline_row": "README.md:51 78.88 ms @ RTX 2070 Super" if a.config == "c4" else None,
                        "parallelism": f"batch-sharded x{world}, 1 scalar all-reduce/step" if world > 1 else "single GPU"},
             "loss_checksum": round(loss_val, 3),
-            "roofline": {"bound": "hbm", "kernel": "k_lsm_small/k_lsm_large (log-softmax over V)",
+            "roofline": {"bound": "hbm", "kernel": "k_lsm_regs / k_lsm_small / k_lsm_large (log-softmax over V)",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "traffic_source": traffic_src,
