@@ -238,7 +238,7 @@ size_t rnnt_amd_debug_redo_offset(int N, int T, int U);
 /*
  * Which arithmetic sweeps the lattice of the workspace-based calls (rnnt_amd_loss, rnnt_amd_loss_compact):
  *   0 auto       probability domain (fp64 mantissa + per-column exponent) where it is the faster
- *                kernel -- long lattices: T >= 640, T >= 2U, U <= 512, padded layout, 2N*ceil(U/64) <= 256 --
+ *                kernel -- long lattices: T >= 640, T >= 2U, U <= 512, padded layout, 2N*ceil(U/64) <= the number of compute units (256) --
  *                and the log domain elsewhere;
  *   1 logdomain  always the reference's arithmetic (fp32 log-sum-exp per cell, core_gather.cu:22-35,106-126);
  *   2 pd         probability domain wherever it is supported (padded layout, U <= 512), log domain elsewhere.

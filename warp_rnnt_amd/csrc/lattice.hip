@@ -465,6 +465,21 @@ int set_lattice_route(int route) {
     return route_setting().exchange(route, std::memory_order_relaxed);
 }
 
+// compute units of the current device (one query per process and device; 256 on MI355X): the probability-domain kernel
+// wants a CU per column block -- one more workgroup than CUs and the last ones start when the first finish
+// (N=25 at U=300: 121 us, N=26: 164 us, log domain 160; profiles/r03_lattice_probe_threshold.txt)
+static int device_cus() {
+    static std::atomic<int> cached[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    int n = cached[dev].load(std::memory_order_relaxed);
+    if (n == 0) {
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        cached[dev].store(n, std::memory_order_relaxed);
+    }
+    return n;
+}
+
 bool pd_shape_supported(int T, int U) {
     (void)T;
     return (U + WAVE - 1) / WAVE <= 8;     // the log-domain kernel behind it must be able to redo a sweep (U <= 512)
@@ -491,7 +506,7 @@ hipError_t launch_lattice(hipStream_t stream, const LatticeArgs& a, int N, int l
         const int nA = (a.U + WAVE - 1) / WAVE;
         // (compact layout: the native entry's 64-bit cell offsets; a.T / a.U are then the launch bounds Tmax / Umax)
         const bool pd_ok = a.redo && a.queue && !a.offs32 && pd_shape_supported(a.T, a.U);
-        bool use_pd = pd_ok && (long long)2 * N * nA <= 256 && a.T >= 640 && a.T >= 2 * a.U;
+        bool use_pd = pd_ok && (long long)2 * N * nA <= device_cus() && a.T >= 640 && a.T >= 2 * a.U;
         if (a.route == ROUTE_LOGDOMAIN) use_pd = false;
         if (a.route == ROUTE_PD) use_pd = pd_ok;
         if (use_pd) {
