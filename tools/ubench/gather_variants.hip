@@ -83,18 +83,18 @@ k_tile(const float* __restrict__ src, const int* __restrict__ labels, float2* __
 // ---------------------------------------------------------------- generalised tile kernel
 // THREADS per workgroup (TD = 32 columns, THREADS/32 frame rows per pass), TT frames per tile, AUX = cache policy
 // bits of the loads (gfx940+: 1 = sc0, 2 = nt, 16 = sc1), NTS = non-temporal stores of the pairs.
-template <int THREADS, int TT, int AUX, bool NTS>
+template <int THREADS, int TT, int AUX, bool NTS, int TD = 32>
 __global__ void __launch_bounds__(THREADS)
 k_tile2(const float* __restrict__ src, const int* __restrict__ labels, float2* __restrict__ ws2, int T, int U, int V,
         int blank, int tiles_t, int tiles_u, unsigned total_bytes) {
-    constexpr int TD = 32, RP = THREADS / 32;
+    constexpr int RP = THREADS / TD;
     __shared__ float2 tile[TT][TD];
     unsigned b = blockIdx.x;
     const int tu = b % tiles_u; b /= tiles_u;
     const int tt = b % tiles_t;
     const int n = b / tiles_t;
     const int t0 = tt * TT, u0 = tu * TD;
-    const int ul = threadIdx.x & (TD - 1), tl0 = threadIdx.x >> 5;
+    const int ul = threadIdx.x % TD, tl0 = threadIdx.x / TD;
     const int u = u0 + ul;
     const size_t nbase = (size_t)n * T * U;
     int lab = blank;
@@ -411,6 +411,23 @@ int main(int argc, char** argv) {
             TILE2(512, 64, 2, false, "tile2 512thr 64x32 nt")
         }
 #undef TILE2
+#define TILE2W(TH, TT, TD, label)                                                                                 \
+    {                                                                                                             \
+        const int tiles_t = (T + TT - 1) / TT, tiles_uw = (U + TD - 1) / TD;                                      \
+        run(label, [&] { k_tile2<TH, TT, 2, false, TD><<<(unsigned)((size_t)N * tiles_t * tiles_uw), TH>>>(src, labels, out, T, U, V, 0, tiles_t, tiles_uw, (unsigned)bytes); }, useful); \
+        check(label);                                                                                             \
+    }
+        if (bytes < ((size_t)1 << 32)) {
+            TILE2W(256, 32, 32, "tile2 nt 32 frames x 32 columns (shipped shape)")
+            TILE2W(256, 32, 64, "tile2 nt 32 frames x 64 columns")
+            TILE2W(256, 16, 64, "tile2 nt 16 frames x 64 columns")
+            TILE2W(256, 16, 128, "tile2 nt 16 frames x 128 columns")
+            TILE2W(256, 8, 128, "tile2 nt 8 frames x 128 columns")
+            TILE2W(256, 8, 256, "tile2 nt 8 frames x 256 columns")
+            TILE2W(512, 16, 128, "tile2 nt 16 frames x 128 columns, 512 threads")
+            TILE2W(256, 32, 32, "tile2 nt 32 frames x 32 columns (again)")
+        }
+#undef TILE2W
     }
     {
         const int tiles_u = (U + 31) / 32;
