@@ -1,5 +1,5 @@
-// Probability-domain alpha / beta lattice sweep for MI355X (gfx950), diagonal-major layout,
-// one workgroup (three waves) per 64-column block of a sweep.
+// Probability-domain alpha / beta lattice sweep for MI355X (gfx950), diagonal-major layout (padded or compact),
+// one workgroup (five waves: one computes, two load, two store) per 64-column block of a sweep.
 //
 // Same anti-diagonal schedule as lattice_ws.hip (read its header first: lanes are lattice columns, a column
 // block of 64 runs behind its left neighbour, blocks of K=8 diagonals, one s_barrier per block).  Two
@@ -28,14 +28,20 @@
 //              multiply + one fma: the stored alpha/beta carry <= 0.5 ulp of rounding plus 2^-23 relative --
 //              nothing accumulates along the sweep (the log-domain chain rounds at |alpha| ~ 6e3 every step:
 //              1e-2 on the gradients at T=1500,U=300, against 8e-4 here).
+//    Off the chain as well, the chain's own range checks (round 3): the extremes of E_left - E_own over the
+//    renormalisations (neighbouring columns may drift further apart than an fp64 holds while every input is in range)
+//    and a final-value check (overflow, NaN and total underflow are sticky); either flags the sweep for the log-domain
+//    kernel like an out-of-range input does.
 //    tests/pd_model.py is the executable statement of this arithmetic (checked on the CPU against fp64).
 //
 // 2. WHERE the column blocks run.  With all column blocks of a sweep in one workgroup (lattice_ws.hip) a
 //    U=300 sweep puts ten waves on the four SIMDs of one CU and the CU's issue rate becomes the limit (95 us at
 //    U=64, 166 us at U=300 for T=1500) while seven eighths of the chip idle at N=16.  Here every column block
 //    is its own workgroup, wherever the dispatcher puts it; the boundary column travels through L2:
-//      * the producer's storer wave publishes, per block, 17 self-validating 8-byte granules {32 data bits,
-//        32-bit tag = launch epoch ^ hash(block)} with one agent-scope (sc1) store instruction;
+//      * the producer's first storer wave publishes, per block of 16 diagonals, 34 self-validating 8-byte granules
+//        {32 data bits, 32-bit tag = launch epoch ^ hash(ring) ^ hash(block), never 0} with one agent-scope (sc1) store
+//        instruction; the rings are zeroed in front of every launch (k_prepare) and the epoch comes from a launch
+//        counter in module-scope device memory, so a granule validates only if THIS launch wrote it;
 //      * the consumer's loader wave requests them two blocks ahead with agent-scope loads (its HBM prefetch
 //        queue), checks the tags when it needs the block and re-polls only while the producer is not there
 //        yet -- so the consumer settles a few microseconds behind the producer and the hand-over costs
