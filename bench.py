@@ -287,11 +287,11 @@ def main():
     xs, ys, xn, yn = make_batch(cfg, rank, dev)
     cells = N * T * U
 
-    # HIP events around the two halves of a step, inside the timed region.  Every step up to 15 steps; beyond that
-    # an evenly spaced sample of >= 8 steps: a recorded event is a barrier packet in the queue (3-4 us of GPU time
-    # each, measured: c2 0.040 ms/step with the sample, 0.051 with three events in every step), which is 1 % of a
-    # 0.9 ms step and a quarter of a 40 us one.
-    ev_stride = max(1, a.steps // 8)
+    # HIP events around the two halves of a step, inside the timed region, on an evenly spaced sample of the steps
+    # (every step up to 5 steps, 5-9 of them beyond): a recorded event is a barrier packet in the queue (3-4 us of
+    # GPU time each, measured: c2 0.040 ms/step with a sample, 0.051 with three events in every step), which is 1 %
+    # of a 0.9 ms step and a quarter of a 40 us one.
+    ev_stride = max(1, a.steps // 5)
     ev_steps = list(range(0, a.steps, ev_stride))
     ev_a = {i: torch.cuda.Event(enable_timing=True) for i in ev_steps}
     ev_b = {i: torch.cuda.Event(enable_timing=True) for i in ev_steps}
