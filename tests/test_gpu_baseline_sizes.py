@@ -296,6 +296,7 @@ def test_c5_full_per_rank_batch_forward():
     import warp_rnnt_amd
     from warp_rnnt_amd import ops
     N, T, U, V, lam = 8, 1500, 300, 10000, 0.01
+    torch.cuda.empty_cache()                              # (blocks cached by earlier tests count as used)
     free, _ = torch.cuda.mem_get_info(dev())
     need = N * T * U * V * 4
     if free < need + 40e9:
@@ -339,3 +340,5 @@ def test_c5_full_per_rank_batch_forward():
             tn, un = int(xn[n]), int(yn[n]) + 1
             np.testing.assert_allclose(g2[n, :tn, :un, 0].sum(axis=1, dtype=np.float64), -1.0, atol=tol)
             np.testing.assert_allclose(g2[n, :tn, :un - 1, 1].sum(axis=0, dtype=np.float64), -(1 + lam), atol=tol)
+    del xs, lp
+    torch.cuda.empty_cache()                              # give the 144 GB back before the next test
