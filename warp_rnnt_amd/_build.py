@@ -54,8 +54,6 @@ VARIANTS = {
     "logdomain": ["-DRNNT_LATTICE_LOGDOMAIN"],
     # the same with ocml expf/log1pf -- the reference's own lse (core.cu:26-39) bit for bit, 4x slower
     "precise": ["-DRNNT_LATTICE_LOGDOMAIN", "-DRNNT_LATTICE_LEGACY", "-DRNNT_PRECISE_LIBM"],
-    # negative control for tests/test_gpu_graph.py: the hand-over epoch without its device-side part
-    "frozen_epoch": ["-DRNNT_PD_FROZEN_EPOCH"],
     # hand-over waits that give up at once: every column block that catches up with its neighbour flags its sweep
     # for the log-domain kernel (the "producer lost" path, which never triggers otherwise)
     "short_spin": ["-DRNNT_PD_SPIN_LIMIT=0"],

@@ -630,9 +630,7 @@ __global__ void __launch_bounds__(5 * WAVE) k_lattice_pd(LatticeArgs a, const in
     __shared__ int wg_bad, s_item;
     // launch epoch = host counter (constant across the replays of a captured graph) + device counter (queue[1]: the
     // library's own per-device launch counter, bumped by k_prepare in front of every launch, replayed or not)
-#ifndef RNNT_PD_FROZEN_EPOCH      // (defined only to show that tests/test_gpu_graph.py fails without the counter)
     a.epoch += (unsigned)a.queue[1];
-#endif
     // work items in column-block-major order from an atomic counter: the workgroup that holds item i knows that
     // every item < i -- in particular its left neighbour, item i - 2N -- is held by a workgroup that has started
     if (threadIdx.x == 0) { s_item = atomicAdd(a.queue, 1); wg_bad = 0; }
