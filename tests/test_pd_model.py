@@ -136,3 +136,28 @@ def test_nan_in_a_live_cell_is_flagged_by_the_chain():
         bad = lp2.copy(); bad[20, 5, ch] = np.nan
         assert not pm.sweep(bad[..., 0], bad[..., 1])[2]
         assert not pm.sweep(bad[..., 0], bad[..., 1], beta=True)[2]
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_lattices_kept_or_flagged_never_silently_wrong(seed):
+    """Random shapes, scales and step inputs: whatever the model KEEPS (ok) is within the accuracy bound of fp64;
+    whatever it cannot carry is flagged.  (The property the GPU kernel is tested for in tests/pd_vs_oracle.py, on
+    inputs the CPU can sweep in milliseconds.)"""
+    rng = np.random.RandomState(1000 + seed)
+    T, U = int(rng.randint(1, 70)), int(rng.randint(2, 70))
+    kind = seed % 3
+    if kind == 0:
+        lp2 = _pairs(T, U, int(rng.choice([3, 9, 40])), seed, float(rng.choice([0.5, 2.0, 6.0])))
+    elif kind == 1:
+        lp2 = _step_case(T, U, int(rng.randint(0, T)), float(rng.uniform(-30, -5)), float(rng.uniform(-3, -0.01)))
+    else:
+        lp2 = _step_case(T, U, int(rng.randint(0, T)), float(rng.uniform(-3, -0.01)), float(rng.uniform(-30, -5)))
+    al, be, ll, ok = pm.lattice(lp2)
+    _, _, a64, b64 = transduce_np.transduce(lp2.astype(np.float64), np.ones(U - 1, int), 0, 0.0, True)
+    if ok:
+        ulp = np.spacing(max(np.abs(a64).max(), np.abs(b64).max()).astype(np.float32))
+        bound = 0.75 * ulp + 4e-7 * np.sqrt(T + U) + 2e-7
+        assert np.abs(al - a64).max() <= bound and np.abs(be - b64).max() <= bound
+        assert abs(ll - b64[0, 0]) <= bound
+    else:
+        assert np.isfinite(b64[0, 0])          # a valid input: the log-domain kernel handles it
