@@ -256,6 +256,8 @@ def main():
         return dry_run(a, world, rank)
     if a.backend != "nccl":
         sys.exit("--backend gloo is a CPU rehearsal: use it with --dry")
+    if local >= torch.cuda.device_count():
+        sys.exit(f"--gpus {a.gpus}: rank {rank} wants cuda:{local} but this node has {torch.cuda.device_count()} GPU(s)")
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
     dist = None
