@@ -430,7 +430,10 @@ __device__ __forceinline__ float half_sum32(float v) {
 }
 constexpr int RG_UN = 2;          // groups per half and wave, loads first (1: 500 us, 2: 462-484, 4: 482-498)
 
-// NT: bit 0 = non-temporal loads, bit 1 = non-temporal stores
+// NT: bit 0 = non-temporal loads, bit 1 = non-temporal stores (both: 462 us for the c4 tensor, neither: 484)
+#ifndef RNNT_LSM_REGS_NT
+#define RNNT_LSM_REGS_NT 3
+#endif
 template <int KR, int NT>
 __global__ void __launch_bounds__(256) k_lsm_regs(const float* __restrict__ x, float* __restrict__ out,
                                                   const int64_t ngroups, const int V) {
@@ -523,14 +526,8 @@ static hipError_t dispatch_lsm(hipStream_t stream, const float* x, float* out, c
             const int64_t per_wg = 4 * RG_UN * 2;               // 4 waves x RG_UN groups x 2 halves
             const int64_t grid = (ngroups + per_wg - 1) / per_wg;
             if (grid < ((int64_t)1 << 31)) {
-                static const int nt = [] { const char* v = getenv("RNNT_LSM_REGS_NT"); return v ? atoi(v) & 3 : 3; }();
-#define LSM_REGS(KR)                                                                                          \
-    case KR:                                                                                                  \
-        if (nt == 0) k_lsm_regs<KR, 0><<<(unsigned)grid, 256, 0, stream>>>(x, out, ngroups, V);               \
-        else if (nt == 1) k_lsm_regs<KR, 1><<<(unsigned)grid, 256, 0, stream>>>(x, out, ngroups, V);          \
-        else if (nt == 2) k_lsm_regs<KR, 2><<<(unsigned)grid, 256, 0, stream>>>(x, out, ngroups, V);          \
-        else k_lsm_regs<KR, 3><<<(unsigned)grid, 256, 0, stream>>>(x, out, ngroups, V);                       \
-        break;
+#define LSM_REGS(KR) \
+    case KR: k_lsm_regs<KR, RNNT_LSM_REGS_NT><<<(unsigned)grid, 256, 0, stream>>>(x, out, ngroups, V); break;
                 switch (kr) { LSM_REGS(1) LSM_REGS(2) LSM_REGS(3) LSM_REGS(4) }
 #undef LSM_REGS
                 const hipError_t e = hipGetLastError();
