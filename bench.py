@@ -53,6 +53,12 @@ def parse():
     p.add_argument("--rccl-group", action="store_true",
                    help="with --gpus 1 and no launcher: still create a real one-rank RCCL process group, so that the "
                         "step carries the per-step all-reduce leg of the multi-GPU path (profiles/r03_rccl_leg.txt)")
+    p.add_argument("--preload-ms", type=float, default=40.0,
+                   help="milliseconds of back-to-back streaming kernels (a copy of a slice of the logits into scratch, "
+                        "not the benchmark step) enqueued in front of the W warm-up steps with no gap, so that the "
+                        "timed steps run in the GPU's sustained-load state, as every step of a training loop does, "
+                        "and not on the 4-14 ms transient that follows load onset after idle "
+                        "(profiles/r03_step_series_cold_start.txt); reported as `preload_ms`, 0 disables")
     p.add_argument("--global-batch", type=int, default=0,
                    help="strong scaling: fix the GLOBAL number of utterances and shard it over the ranks "
                         "(default 0 = weak scaling, the config's per-GPU batch on every rank)")
@@ -330,6 +336,19 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if a.preload_ms > 0:
+        # Sustained-load conditioning, disclosed in the JSON line.  A GPU that goes from idle to a streaming load slows
+        # both kernels by 10-15 % from ~4 to ~14 ms after the onset, then settles (tools/step_series.py: steps 3-12 of a
+        # cold process; with 30 ms of back-to-back streaming kernels in front, step 0 already runs at the settled
+        # rate).  W = 5 warm-up steps are 4.5 ms: without this the timed steps sit exactly on that transient, which no
+        # step of a training loop ever sees.  Not the benchmark step and not extra warm-up steps: plain copies of a
+        # <= 1 GiB slice of the logits into scratch, enqueued with no synchronisation in front of the W warm-up steps.
+        src = xs.view(-1)[: min(xs.numel(), 1 << 28)]
+        scratch = torch.empty_like(src)
+        per_copy_ms = 2.0 * src.numel() * 4 / 5.0e12 * 1e3          # at ~5 TB/s
+        for _ in range(int(a.preload_ms / per_copy_ms) + 1):
+            torch.mul(src, 1.0, out=scratch)
+        del scratch
     for _ in range(a.warmup):
         step(last=True)          # the closing reduction is warmed up too
     fence()
@@ -464,6 +483,7 @@ def main():
                                    "algorithmic_bytes": g_bytes, "kernels_ms": round(g_ms, 4)},
             "rccl_ranks": rccl_ranks,
             "rccl_group": dist is not None,     # True: every step ended in costs.sum() + one RCCL all-reduce
+            "preload_ms": a.preload_ms,         # streaming copies enqueued in front of the warm-up steps (not steps)
         }
         out.update(extras)
         if not a.no_cpu_baseline and world == 1:   # the CPU leg is reported at N=1 only
