@@ -16,6 +16,15 @@ RNNT_LATTICE=logdomain python $R/bench.py --no-cpu-baseline > $OUT/bench_c4_logd
 rocprofv3 --kernel-trace --stats -d $OUT/stats_c4 -o c4 -- python $R/bench.py --steps 50 --warmup 5 --no-cpu-baseline > $OUT/bench_c4_profiled.json 2>/dev/null
 rocprofv3 --kernel-trace --stats -d $OUT/stats_c3 -o c3 -- python $R/bench.py --config c3 --steps 50 --warmup 5 --no-cpu-baseline > /dev/null 2>&1
 rocprofv3 --kernel-trace --stats -d $OUT/stats_c2 -o c2 -- python $R/bench.py --config c2 --steps 100 --warmup 5 --no-cpu-baseline > /dev/null 2>&1
+# SLIM=1: only the bench lines and the kernel-trace summaries (the counter passes of an earlier collection under the same
+# tag stay where they are; tools/summarise_profiles.py reads whatever gpurun_out/$TAG holds)
+if [ "${SLIM:-0}" = 1 ]; then
+  cd $R
+  python $R/bench.py --no-cpu-baseline --rccl-group > $OUT/bench_c4_rccl_group.json 2>> $OUT/bench.err
+  python $R/bench.py --no-cpu-baseline --steps 20 --warmup 5 --preload-ms 0 > $OUT/bench_c4_cold_start.json 2>> $OUT/bench.err
+  ls $OUT
+  exit 0
+fi
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -o c4 -- python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -o c4 -- python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline > /dev/null 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch_c3 -o c3 -- python $R/bench.py --config c3 --steps 10 --warmup 2 --no-cpu-baseline > /dev/null 2>&1

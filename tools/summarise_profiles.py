@@ -63,7 +63,8 @@ def main():
     for f in glob.glob(os.path.join(SRC, "table_*.md")):
         shutil.copy(f, os.path.join(DST, f"{TAG}_" + os.path.basename(f)))
     for name in ("parity_errors.json", "lattice_probe.txt", "ubench_pd_steps.txt", "host_overhead.txt",
-                 "bench_c4_logdomain_lattice.json", "bench_c4_rccl_group.json", "graph_probe.txt",
+                 "bench_c4_logdomain_lattice.json", "bench_c4_rccl_group.json", "bench_c4_cold_start.json",
+                 "graph_probe.txt",
                  "ubench_gather_variants.txt"):
         if os.path.exists(os.path.join(SRC, name)):
             shutil.copy(os.path.join(SRC, name), os.path.join(DST, f"{TAG}_" + name))
