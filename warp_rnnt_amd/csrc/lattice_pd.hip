@@ -320,6 +320,16 @@ __device__ __forceinline__ void sweep(const LatticeArgs& a, const Item it, const
     const unsigned tag_in = ring_tag(a.epoch, (unsigned)(sweep_id * (nA - 1) + (idx - 1)));
     const unsigned tag_out = ring_tag(a.epoch, (unsigned)(sweep_id * (nA - 1) + idx));
     (void)tag_in; (void)tag_out;
+#ifdef RNNT_PD_STATS       // diagnostics build (tools/pd_trace.py): a (sweep, column block, interval) table of
+                           // s_memrealtime stamps behind the rings -- 16 words per interval: 0 compute start, 1 time the
+                           // first loader polled for the neighbour, 2/3 loader start, 4/5 storer start, 6 compute end,
+                           // 7/8 loader end, 9/10 storer end.  Costs a few per cent; never part of the product build.
+    u64* const trace = a.mail + (size_t)2 * (gridDim.x / nA / 2) * (nA - 1) * a.mail_blocks * GPITCH +
+                       ((sweep_id * nA + idx) * (size_t)(a.mail_blocks + 8)) * 16;
+#define RNNT_PD_STAMP(slot, word) do { if (lane == 0 && (slot) + 4 >= 0) trace[16 * ((slot) + 4) + (word)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define RNNT_PD_STAMP(slot, word) do { } while (0)
+#endif
 
     const int rowb_lp = U * 8, rowb_out = U * 4;
     // row (forward diagonal mod T) of the first diagonal of block `lo`; rows advance by one per diagonal
@@ -397,8 +407,14 @@ __device__ __forceinline__ void sweep(const LatticeArgs& a, const Item it, const
                 // block has caught up with its neighbour.  Let the neighbour get LAG blocks ahead (or finish)
                 // before going on, so that the look-ahead requests of the following blocks find their data --
                 // otherwise every block would pay a polling round trip (~1.3 us against ~0.4 us of work).
+#ifdef RNNT_PD_STATS
+                const u64 t_wait = __builtin_amdgcn_s_memrealtime();
+#endif
                 mail_wait(min(lb + LAG, hi_left - 1));
                 g = mail_wait(lb);
+#ifdef RNNT_PD_STATS
+                if (lane == 0) trace[16 * (lb + 4) + 1] = __builtin_amdgcn_s_memrealtime() - t_wait;
+#endif
             }
             if (lane < GRAN) sm.mail_in[lb & (MSLOTS - 1)][lane] = (unsigned)g;
         };
@@ -407,6 +423,7 @@ __device__ __forceinline__ void sweep(const LatticeArgs& a, const Item it, const
         auto l_step = [&](const int p, auto ph, auto guarded) {
             constexpr int PH = decltype(ph)::value;           // p mod NBR
             constexpr bool GUARDED = decltype(guarded)::value;
+            RNNT_PD_STAMP(p, 2 + half);
             if (!GUARDED || (p >= lo && p < hi)) {
                 float* dst = &sm.probs[p & (PSLOTS - 1)][lane * PSTRIDE + 4 * k0];
                 const bool full = !GUARDED || full_block(p);
@@ -452,6 +469,7 @@ __device__ __forceinline__ void sweep(const LatticeArgs& a, const Item it, const
             if constexpr (does_mail) { if (!GUARDED || (p - 1 >= lo && p - 1 < hi_left)) mail_stage(p - 1, mregs[PH]); }
             if (!GUARDED || (p + DLOAD >= lo && p + DLOAD < hi)) load_block(regs[(PH + DLOAD) % NBR]);
             if constexpr (does_mail) { if (!GUARDED || (p + 1 >= lo && p + 1 < hi_left)) mregs[(PH + DLOAD) % NBR] = mail_request(p + 1); }
+            RNNT_PD_STAMP(p, 7 + half);
             block_barrier();
         };
         auto l_any = [&](const int p, auto guarded) {
@@ -497,6 +515,7 @@ __device__ __forceinline__ void sweep(const LatticeArgs& a, const Item it, const
         auto s_step = [&](const int p, auto guarded) {
             constexpr bool GUARDED = decltype(guarded)::value;
             const int ps = p - 3;
+            RNNT_PD_STAMP(p, 4 + half);
             if (!GUARDED || (ps >= lo && ps < hi)) {
                 if (has_right && half == 0 && lane < GRAN) {      // (has_right: compile time)
                     const u64 g = ((u64)block_tag(tag_out, ps) << 32) | sm.mail_out[ps & (MSLOTS - 1)][lane];
@@ -538,6 +557,7 @@ __device__ __forceinline__ void sweep(const LatticeArgs& a, const Item it, const
                     }
                 }
             }
+            RNNT_PD_STAMP(p, 9 + half);
             block_barrier();
         };
         int g = 0;
@@ -565,6 +585,7 @@ __device__ __forceinline__ void sweep(const LatticeArgs& a, const Item it, const
     Cell2 bufA[K], bufB[K];
     auto do_block = [&](const int lb, const Cell2 (&cur)[K], Cell2 (&nxt)[K]) {
         const int d0 = lb * K;
+        RNNT_PD_STAMP(lb, 0);
         double seed[K];
         int e_mail0 = 0, e_mail1 = 0;
         if constexpr (has_left) {
@@ -591,6 +612,7 @@ __device__ __forceinline__ void sweep(const LatticeArgs& a, const Item it, const
         if (full) RNNT_PD_CALL(false, HAS_LEFT, HAS_RIGHT);
         else RNNT_PD_CALL(true, HAS_LEFT, HAS_RIGHT);
 #undef RNNT_PD_CALL
+        RNNT_PD_STAMP(lb, 6);
         block_barrier();
     };
     int g = 0;
@@ -684,7 +706,11 @@ size_t pd_mail_blocks(int T, int U) { return (size_t)(T + U - 1 + pd::K - 1) / p
 size_t pd_mail_bytes(int N, int T, int U) {
     const int nA = (U + WAVE - 1) / WAVE;
     if (nA < 2 || !pd_shape_supported(T, U)) return 0;     // one column block, or a shape the kernel never takes
-    return (size_t)2 * N * (nA - 1) * pd_mail_blocks(T, U) * pd::GPITCH * sizeof(pd::u64);
+    size_t bytes = (size_t)2 * N * (nA - 1) * pd_mail_blocks(T, U) * pd::GPITCH * sizeof(pd::u64);
+#ifdef RNNT_PD_STATS       // the stamp table of the diagnostics build, behind the rings
+    bytes += (size_t)2 * N * nA * (pd_mail_blocks(T, U) + 8) * sizeof(pd::u64) * 16;
+#endif
+    return bytes;
 }
 
 // Needs a.redo, a.queue = a.redo + 2N with the launch counter behind it (and a.mail when U > 64); zeroes redo and
