@@ -10,7 +10,11 @@ N=16, T=1500, U=300, V=50, gather=True -- the row the reference published as 78.
 16N = configs[3] at N=8) and the per-step scalar loss is summed across ranks with one RCCL
 all-reduce.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c2|c3|c4|c5]
+Timing: [--preload-ms of streaming copies, see its help] -> W untimed warm-up steps -> barrier + synchronize ->
+exactly K timed steps -> barrier + synchronize; ms_per_step = that wall time / K, MAX over ranks.  The preload is not
+the benchmark step and is reported in the JSON line (`preload_ms`; 0 = measure from a cold start).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c2|c3|c4|c5] [--preload-ms P]
 """
 import argparse
 import json
