@@ -180,11 +180,13 @@ def test_calls_stress():
 # ----------------------------------------------------------------------------
 # 4. prologue kernels
 # ----------------------------------------------------------------------------
-# (1024 / 2560 / 5120 / 12288 / 16384: where the launcher changes kernel or workgroup shape, prologue.hip: dispatch_lsm;
+# (1024 / 2048 / 3072 / 4096 / 5632 / 6144 / 8192 / 12288 / 16384: where the launcher changes kernel or workgroup
+#  shape, prologue.hip: dispatch_lsm, each with its neighbour on the other side;
 #  20 ... 128: the rows-in-registers kernel with 1, 2, 3 and 4 rows per group -- 28 / 50 are c2 / c4 -- and its
 #  neighbours that fall back to the LDS-staged one; 1003 rows: a tail that is no whole group)
 @pytest.mark.parametrize("V", [2, 3, 5, 20, 24, 28, 30, 32, 40, 42, 48, 50, 51, 64, 100, 126, 128, 257, 600, 1024, 1028,
-                               1030, 2560, 2564, 5000, 5120, 5124, 10000, 12288, 12292, 16384, 16388, 20000])
+                               1030, 2048, 2052, 2560, 2564, 3072, 3076, 4096, 4100, 5000, 5120, 5124, 5632, 5636,
+                               6144, 6148, 8192, 8196, 10000, 12288, 12292, 16384, 16388, 20000])
 def test_log_softmax_kernel(V):
     from warp_rnnt_amd import ops
     rows = 1003 if V < 2000 else 77

@@ -585,23 +585,33 @@ static hipError_t dispatch_lsm(hipStream_t stream, const float* x, float* out, c
         }
 #endif
         if constexpr (MODE == LSM_NORM) {
-            // The read + write stream wants about two float4 per thread and (nearly) every thread busy in every pass,
-            // whatever that does to the residency (profiles/r02_lsm_large_variants.txt, threads x passes, us for
-            // ~1.9 GB in + out: V=3000 256x3 734 / 384x2 663; V=5000 256x5 710 / 512x3 689-705 / 640x2 662-673;
-            // V=8192 256x8 687 / 1024x2 666; V=10000 512x5 870 / 1024x3 828-834 / 896x3 811; V=16384 512x8 707 /
-            // 1024x4 723).  Thread counts in steps of two waves; the count is a template parameter on purpose (the
-            // same kernel with blockDim.x read at run time: 780 us at V=5000).
+            // The read + write stream wants about two float4 per thread and (nearly) every thread busy in every pass;
+            // workgroups of 512 or 1024 threads (which tile a CU's 2048 exactly) beat the sizes in between.  Round 2
+            // (profiles/r02_lsm_large_variants.txt, threads x passes, us for ~1.9 GB in + out): V=3000 256x3 734 /
+            // 384x2 663; V=8192 256x8 687 / 1024x2 666; V=10000 512x5 870 / 1024x3 828-834 / 896x3 811; V=16384 512x8
+            // 707 / 1024x4 723.  Re-swept in round 3 with the non-temporal policies in place
+            // (profiles/r03_xcd_run_order_probe.txt part 3, profiles/r03_lg_cover_ab.txt; TB/s in + out): V=5000 640x2
+            // 5.71 / 512x3 5.79-5.82 (c3 in bench.py: 0.696 -> 0.680 ms); V=5120 640x2 5.90 / 512x3 6.10; V=5600 768x2
+            // 5.96 / 512x3 6.17; V=6144 768x2 6.23 / 512x3 5.99 / 1024x2 6.11; V=7168 896x2 5.90 / 1024x2 6.16.
+            // The thread count is a template parameter on purpose (the same kernel with blockDim.x read at run
+            // time: 780 us at V=5000).
             const int nvec = V >> 2;
-            const int passes = nvec <= 2048 ? 2 : 3;
-            int th = (nvec + 128 * passes - 1) / (128 * passes) * 128;
-            th = th < 256 ? 256 : th;
 #define LGN(TH, NV) case TH: k_lsm_large<MODE, TH, NV><<<grid, TH, 0, stream>>>(x, out, labels, rows, V, T, U, blank, bw); break;
             if (nvec > 3072) {
                 k_lsm_large<MODE, 512, 8><<<grid, 512, 0, stream>>>(x, out, labels, rows, V, T, U, blank, bw);
-            } else if (passes == 2) {
-                switch (th) { LGN(256, 2) LGN(384, 2) LGN(512, 2) LGN(640, 2) LGN(768, 2) LGN(896, 2) LGN(1024, 2) }
-            } else {
+            } else if (nvec > 2048) {
+                const int th = (nvec + 383) / 384 * 128;
                 switch (th) { LGN(768, 3) LGN(896, 3) LGN(1024, 3) }
+            } else if (nvec > 1536) {
+                k_lsm_large<MODE, 1024, 2><<<grid, 1024, 0, stream>>>(x, out, labels, rows, V, T, U, blank, bw);
+            } else if (nvec > 1408) {
+                k_lsm_large<MODE, 768, 2><<<grid, 768, 0, stream>>>(x, out, labels, rows, V, T, U, blank, bw);
+            } else if (nvec > 1024) {
+                k_lsm_large<MODE, 512, 3><<<grid, 512, 0, stream>>>(x, out, labels, rows, V, T, U, blank, bw);
+            } else {
+                int th = (nvec + 255) / 256 * 128;
+                th = th < 256 ? 256 : th;
+                switch (th) { LGN(256, 2) LGN(384, 2) LGN(512, 2) }
             }
 #undef LGN
         } else {
