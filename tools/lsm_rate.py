@@ -16,6 +16,7 @@ if len(sys.argv) > 1:
 variants = os.environ.get("LG_VARIANTS", "").split() or [None]
 chunks = os.environ.get("XCD_CHUNKS", "").split() or [None]      # RNNT_XCD_CHUNK values (probe build): XCD run lengths
 cases = [(V, gb, v, c) for V, gb in cases for v in variants for c in chunks]
+backward = bool(os.environ.get("LSM_BACKWARD"))               # time ops.log_softmax_backward (three streams) instead
 for V, gb, variant, chunk in cases:
     if chunk is not None:
         os.environ["RNNT_XCD_CHUNK"] = chunk
@@ -29,17 +30,24 @@ for V, gb, variant, chunk in cases:
     rows = int(gb * 1e9 / 4 / V)
     x = torch.randn(rows, V, device=dev)
     out = torch.empty_like(x)
+    if backward:
+        y = ops.log_softmax(x)
+        run = lambda: ops.log_softmax_backward(x, y, grad_in=out)
+    else:
+        run = lambda: ops.log_softmax(x, out=out)
     for _ in range(80):
-        ops.log_softmax(x, out=out)
+        run()
     ts = []
     for _ in range(5):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(10):
-            ops.log_softmax(x, out=out)
+            run()
         e1.record()
         torch.cuda.synchronize()
         ts.append(e0.elapsed_time(e1) / 10)
     ms = statistics.median(ts)
-    print(f"V={V:6d} rows={rows:9d} in={rows * V * 4 / 1e9:5.2f} GB  {ms * 1e3:8.1f} us  {2 * rows * V * 4 / ms / 1e9:6.2f} TB/s", flush=True)
+    streams = 3 if backward else 2
+    print(f"V={V:6d} rows={rows:9d} in={rows * V * 4 / 1e9:5.2f} GB  {ms * 1e3:8.1f} us  {streams * rows * V * 4 / ms / 1e9:6.2f} TB/s"
+          f"{' (backward: dy, y in, dx out)' if backward else ''}", flush=True)
     del x, out
