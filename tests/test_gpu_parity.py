@@ -183,8 +183,11 @@ def test_calls_stress():
 # (1024 / 2048 / 3072 / 4096 / 5632 / 6144 / 8192 / 12288 / 16384: where the launcher changes kernel or workgroup
 #  shape, prologue.hip: dispatch_lsm, each with its neighbour on the other side;
 #  20 ... 128: the rows-in-registers kernel with 1, 2, 3 and 4 rows per group -- 28 / 50 are c2 / c4 -- and its
-#  neighbours that fall back to the LDS-staged one; 1003 rows: a tail that is no whole group)
-@pytest.mark.parametrize("V", [2, 3, 5, 20, 24, 28, 30, 32, 40, 42, 48, 50, 51, 64, 100, 126, 128, 257, 600, 1024, 1028,
+#  neighbours that fall back to the LDS-staged one; 1003 rows: a tail that is no whole group;
+#  132 ... 1024: the row-in-registers kernel with small workgroups where a row fills its cover (252, 256, 484, 500, 512,
+#  724, 768, 964, 1000, 1024) and the LDS-staged one where it does not (132, 244, 248, 480, 600, 720, 960))
+@pytest.mark.parametrize("V", [2, 3, 5, 20, 24, 28, 30, 32, 40, 42, 48, 50, 51, 64, 100, 126, 128, 132, 244, 248, 252, 256,
+                               257, 480, 484, 500, 512, 600, 720, 724, 768, 960, 964, 1000, 1024, 1028,
                                1030, 2048, 2052, 2560, 2564, 3072, 3076, 4096, 4100, 5000, 5120, 5124, 5632, 5636,
                                6144, 6148, 8192, 8196, 10000, 12288, 12292, 16384, 16388, 20000])
 def test_log_softmax_kernel(V):

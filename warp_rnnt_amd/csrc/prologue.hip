@@ -537,6 +537,28 @@ static hipError_t dispatch_lsm(hipStream_t stream, const float* x, float* out, c
             }
         }
     }
+    if constexpr (MODE == LSM_NORM) {
+        // 128 < V <= 1024 whose rows fill a cover of 64 ... 256 threads x one float4 (or an exact 64x2 / 64x3 / 128x2):
+        // the row-in-registers kernel below, one row per small workgroup, instead of the LDS-staged tiles.  Measured
+        // round 3 (tools/lsm_rate.py, 1.44 GB in, TB/s in + out, LDS-staged -> registers; profiles/r03_lsm_midv_probe.txt):
+        // V=256 5.82 -> 6.44, 496 5.33 -> 6.12, 500 5.14 -> 5.90, 512 5.77 -> 6.47, 768 5.58 -> 6.15, 980 5.26 -> 6.00,
+        // 1000 5.14 -> 6.10, 1024 5.76 -> 6.59; with 94 % of the lanes busy still +4 ... +10 % (484, 724, 964), below
+        // that -- and below 98 % for a single wave (V=244: 5.53 -> 5.23) -- the tiles win (V=200, 400, 600: 78 / 59 %).
+        if (aligned && V % 4 == 0 && V > 128 && V <= 1024) {
+            const int nvec = V >> 2, th = (nvec + 63) / 64 * 64;
+            const unsigned grid = (unsigned)(rows < (1 << 22) ? rows : (1 << 22));
+#define LGR(TH, NV) { k_lsm_large<MODE, TH, NV><<<grid, TH, 0, stream>>>(x, out, labels, rows, V, T, U, blank, bw); return hipGetLastError(); }
+            if (nvec == 64) LGR(64, 1)
+            if (nvec == 128) LGR(64, 2)
+            if (nvec == 192) LGR(64, 3)
+            if (nvec == 256) LGR(128, 2)
+            if (th == 64 && nvec >= 63) LGR(64, 1)
+            if (th == 128 && nvec * 100 >= th * 94) LGR(128, 1)
+            if (th == 192 && nvec * 100 >= th * 94) LGR(192, 1)
+            if (th == 256 && nvec * 100 >= th * 94) LGR(256, 1)
+#undef LGR
+        }
+    }
     if (aligned && V <= 1024) {
         int L = 1;
         while (L < 64 && L * 16 < V) L <<= 1;          // <= 16 columns per lane
