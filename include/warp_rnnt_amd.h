@@ -252,6 +252,18 @@ size_t rnnt_amd_debug_redo_offset(int N, int T, int U);
 int rnnt_amd_set_lattice(int route);
 int rnnt_amd_get_lattice(void);
 
+/*
+ * Which KERNEL serves the log-domain arithmetic where two can (speed only -- they share the step function and produce
+ * the same bits, tests/test_gpu_wd.py):
+ *   0 by shape   (default)
+ *   1 ws         all column blocks of a sweep in one workgroup (csrc/lattice_ws.hip; U <= 512)
+ *   2 wd         one workgroup per 64-column block, boundary columns through L2 rings (csrc/lattice_wd.hip; any U)
+ * Process-wide, read once per call; initial value from the environment variable RNNT_LOGDOMAIN_KERNEL (ws | wd).
+ * Returns the previous setting, or -1 for an unknown value.  A tuning and test knob, not part of the numerics contract.
+ */
+int rnnt_amd_set_logdomain_kernel(int kernel);
+int rnnt_amd_get_logdomain_kernel(void);
+
 /* Library version, for the host-side loader. */
 int rnnt_amd_version(void);
 

@@ -1,0 +1,171 @@
+"""The distributed log-domain lattice kernel (csrc/lattice_wd.hip: one workgroup per 64-column block, boundary
+columns through L2 rings) against the single-workgroup one (csrc/lattice_ws.hip) and the oracle.
+
+Both kernels call the same step function (csrc/lattice_step.h), so they must agree BIT FOR BIT on costs and gradients
+whatever the shape, the batch size, the layout and the timing of the hand-overs -- that is what makes the kernel choice a
+pure speed knob inside the `logdomain` route (the reference's arithmetic, core_gather.cu:22-35,106-126)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+import warp_rnnt_amd
+from helpers import make_case, np_log_softmax32
+from warp_rnnt_amd import ops
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+DEV = torch.device("cuda:0")
+
+
+def _pairs(logits, labels, blank=0):
+    lp = np_log_softmax32(logits)
+    return oracle.gather_f32(lp, labels, blank)
+
+
+def _run(lp2, xn, yn, kernel, lam=0.0):
+    old_r = warp_rnnt_amd.set_lattice("logdomain")
+    old_k = warp_rnnt_amd.set_logdomain_kernel(kernel)
+    try:
+        costs, grads = ops.loss(lp2, None, xn, yn, ops.IN_LOG_PROBS_GATHERED, ops.GRADS_GATHERED, fastemit_lambda=lam)
+        torch.cuda.synchronize()
+        return costs, grads
+    finally:
+        warp_rnnt_amd.set_lattice(old_r)
+        warp_rnnt_amd.set_logdomain_kernel(old_k)
+
+
+# (N, T, U, ragged): one, two and many column blocks; widths one short of / one beyond a block; lattices shorter than a
+# block is wide; batches that put several workgroups on every CU
+SHAPES = [(3, 37, 70, True), (2, 5, 130, False), (4, 200, 65, True), (2, 150, 64, False), (16, 150, 40, False),
+          (5, 333, 129, True), (4, 600, 300, True), (2, 64, 512, False), (70, 90, 200, True), (3, 1, 100, True),
+          (2, 700, 257, False), (300, 40, 130, True)]
+
+
+@pytest.mark.parametrize("N,T,U,ragged", SHAPES)
+def test_same_bits_as_the_single_workgroup_kernel(N, T, U, ragged):
+    logits, labels, xn, yn = make_case(1000 + N + T + U, N, T, U, 6, ragged=ragged)
+    if ragged and N > 2:
+        yn[1] = 0                       # an utterance without labels (single-column scan)
+        xn[2] = max(1, T // 3)
+    lp2 = torch.tensor(_pairs(logits, labels), device=DEV)
+    txn, tyn = torch.tensor(xn, device=DEV), torch.tensor(yn, device=DEV)
+    c_ws, g_ws = _run(lp2, txn, tyn, "ws", lam=0.01)
+    c_wd, g_wd = _run(lp2, txn, tyn, "wd", lam=0.01)
+    assert torch.equal(c_ws, c_wd)
+    assert torch.equal(g_ws, g_wd)
+    if N * T * U <= 400_000:
+        o = oracle.rnnt_loss_f32(lp2.cpu().numpy(), None, xn, yn, blank=-1, fastemit_lambda=0.01)
+        # (two fp32 implementations of one operation order: 1e-4 up to T+U ~ 200, the rounding of |alpha| beyond)
+        np.testing.assert_allclose(c_wd.cpu().numpy(), o["costs"], rtol=1e-5)
+        np.testing.assert_allclose(g_wd.cpu().numpy(), o["grads"], atol=1e-4 if T + U <= 250 else 3e-4)
+
+
+def test_wider_than_one_workgroup_can_sweep():
+    """U > 512: the single-workgroup kernel cannot take it (lattice.hip's striped kernel does); the distributed one
+    simply has more column blocks.  Against the oracle."""
+    N, T, U = 2, 60, 700
+    logits, labels, xn, yn = make_case(77, N, T, U, 5, ragged=True)
+    lp2 = torch.tensor(_pairs(logits, labels), device=DEV)
+    txn, tyn = torch.tensor(xn, device=DEV), torch.tensor(yn, device=DEV)
+    c_wd, g_wd = _run(lp2, txn, tyn, "wd")
+    c_st, g_st = _run(lp2, txn, tyn, "ws")      # (falls through to the striped kernel at this width)
+    o = oracle.rnnt_loss_f32(lp2.cpu().numpy(), None, xn, yn, blank=-1)
+    np.testing.assert_allclose(c_wd.cpu().numpy(), o["costs"], rtol=1e-5)
+    np.testing.assert_allclose(g_wd.cpu().numpy(), o["grads"], atol=3e-4)
+    np.testing.assert_allclose(c_st.cpu().numpy(), o["costs"], rtol=1e-5)
+    np.testing.assert_allclose(g_st.cpu().numpy(), o["grads"], atol=3e-4)
+
+
+def test_results_do_not_depend_on_timing_or_workspace_contents():
+    """Replays on a workspace that is scribbled over between calls (stale rings, stale tags) and under a competing
+    stream of copies: the same bits every time."""
+    N, T, U = 6, 400, 200
+    logits, labels, xn, yn = make_case(5, N, T, U, 4, ragged=True)
+    lp2 = torch.tensor(_pairs(logits, labels), device=DEV)
+    txn, tyn = torch.tensor(xn, device=DEV), torch.tensor(yn, device=DEV)
+    c0, g0 = _run(lp2, txn, tyn, "ws")
+    side = torch.cuda.Stream()
+    junk = torch.empty(64 << 20, dtype=torch.uint8, device=DEV)
+    for it in range(6):
+        with torch.cuda.stream(side):
+            for _ in range(8):
+                junk.copy_(junk.flip(0))
+        # churn the allocator so that the next workspace reuses memory with other contents
+        scrib = torch.randint(0, 255, (ops._lib.load().rnnt_amd_workspace_size(N, T, U),), dtype=torch.uint8, device=DEV)
+        del scrib
+        c, g = _run(lp2, txn, tyn, "wd")
+        assert torch.equal(c, c0) and torch.equal(g, g0), it
+    torch.cuda.synchronize()
+
+
+def test_lost_hand_over_is_redone_by_the_single_workgroup_kernel():
+    """`short_spin` build: a hand-over wait gives up at the first poll, so every column block that catches up with its
+    neighbour runs on stale boundary values, flags its sweep, and the kernel launched behind redoes it.  Same bits."""
+    from warp_rnnt_amd import _build
+    lib = _build.build(variant="short_spin")
+    code = r'''
+import sys, numpy as np, torch
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import warp_rnnt_amd, oracle
+from warp_rnnt_amd import ops
+from helpers import make_case, np_log_softmax32
+dev = torch.device("cuda:0")
+L = ops._lib.load()
+bad = 0
+for (N, T, U) in [(4, 500, 300), (16, 300, 130), (40, 200, 200)]:
+    logits, labels, xn, yn = make_case(N + T, N, T, U, 5, ragged=True)
+    lp2 = torch.tensor(oracle.gather_f32(np_log_softmax32(logits), labels, 0), device=dev)
+    txn, tyn = torch.tensor(xn, device=dev), torch.tensor(yn, device=dev)
+    res = {}
+    for k in ("ws", "wd"):
+        warp_rnnt_amd.set_lattice("logdomain"); warp_rnnt_amd.set_logdomain_kernel(k)
+        ws = torch.empty((L.rnnt_amd_workspace_size(N, T, U),), dtype=torch.uint8, device=dev)
+        costs = torch.empty((N,), device=dev); grads = torch.empty((N, T, U, 2), device=dev)
+        st = L.rnnt_amd_loss(torch.cuda.current_stream().cuda_stream, ws.data_ptr(), 1, lp2.data_ptr(), None,
+                             txn.data_ptr(), tyn.data_ptr(), costs.data_ptr(), grads.data_ptr(), 0, N, T, U, 2, 0, 0.0)
+        assert st == 0
+        torch.cuda.synchronize()
+        off = L.rnnt_amd_debug_redo_offset(N, T, U)
+        flags = ws[off:off + 8 * N].view(torch.int32).clone()
+        res[k] = (costs, grads, flags)
+    assert torch.equal(res["ws"][0], res["wd"][0]) and torch.equal(res["ws"][1], res["wd"][1]), (N, T, U)
+    bad += int((res["wd"][2] & 2).ne(0).sum().item())
+assert bad > 0, "the short-spin build never lost a hand-over: the redo path was not exercised"
+print("WD_SHORT_SPIN_OK", bad)
+''' % (os.path.dirname(HERE), HERE)
+    env = dict(os.environ, WARP_RNNT_AMD_LIB=lib)
+    out = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                         timeout=900)
+    text = out.stdout.decode()
+    assert out.returncode == 0 and "WD_SHORT_SPIN_OK" in text, text[-4000:]
+
+
+def test_compact_layout_same_bits():
+    """The native compact entry (64-bit cell offsets): per-utterance planes, rings sized by the launch bounds."""
+    import warp_rnnt
+    N, T, U, V = 5, 220, 150, 7
+    logits, labels, xn, yn = make_case(9, N, T, U, V, ragged=True)
+    lp = torch.tensor(np_log_softmax32(logits), device=DEV)
+    tl, txn, tyn = (torch.tensor(a, device=DEV) for a in (labels, xn, yn))
+    # pack: (sum_n T_n*U_n, V) rows, labels concatenated -- what rnnt_loss(compact=True) takes (__init__.py:109-116)
+    rows = torch.cat([lp[n, :xn[n], :yn[n] + 1].reshape(-1, V) for n in range(N)]).contiguous()
+    labs = torch.cat([tl[n, :yn[n]] for n in range(N)]).contiguous()
+    out = {}
+    for k in ("ws", "wd"):
+        old_r = warp_rnnt_amd.set_lattice("logdomain")
+        old_k = warp_rnnt_amd.set_logdomain_kernel(k)
+        try:
+            x = rows.clone().requires_grad_(True)
+            loss = warp_rnnt.rnnt_loss(x, labs, txn, tyn, compact=True, reduction="sum")
+            loss.backward()
+            torch.cuda.synchronize()
+            out[k] = (loss.detach().clone(), x.grad.clone())
+        finally:
+            warp_rnnt_amd.set_lattice(old_r)
+            warp_rnnt_amd.set_logdomain_kernel(old_k)
+    assert torch.equal(out["ws"][0], out["wd"][0]) and torch.equal(out["ws"][1], out["wd"][1])

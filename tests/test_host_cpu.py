@@ -69,12 +69,23 @@ def test_lattice_route_is_a_runtime_setting_and_sizes_do_not_depend_on_it():
         assert L.rnnt_amd_set_lattice(7) == -1 and warp_rnnt_amd.get_lattice() == "auto"   # unknown value: no change
     finally:
         warp_rnnt_amd.set_lattice(start)
-    # hand-over rings are reserved for shapes the probability-domain kernel can take (more than one column block,
-    # U <= 512) and for no others
+    # hand-over rings are reserved for every shape with more than one column block (the probability-domain kernel's
+    # up to U = 512, the distributed log-domain kernel's -- one granule per diagonal -- beyond) and for no others
     cells = lambda n, t, u: n * t * u * 16
     assert L.rnnt_amd_workspace_size(16, 1500, 64) - cells(16, 1500, 64) < 1 << 16
     assert L.rnnt_amd_workspace_size(16, 1500, 300) - cells(16, 1500, 300) > 1 << 20
-    assert L.rnnt_amd_workspace_size(2, 100, 1100) - cells(2, 100, 1100) < 1 << 16
+    wide = L.rnnt_amd_workspace_size(2, 100, 1100) - cells(2, 100, 1100)
+    assert 2 * 2 * 17 * (1199 + 8) * 8 <= wide < 1 << 20
+    # the kernel choice inside the log-domain route: the same kind of setting, and sizes do not depend on it either
+    try:
+        assert warp_rnnt_amd.set_logdomain_kernel("wd") == "auto" and L.rnnt_amd_get_logdomain_kernel() == 2
+        assert L.rnnt_amd_workspace_size(16, 1500, 300) == sizes["auto"][0]
+        assert warp_rnnt_amd.set_logdomain_kernel("ws") == "wd"
+        assert L.rnnt_amd_set_logdomain_kernel(9) == -1 and L.rnnt_amd_get_logdomain_kernel() == 1
+        with pytest.raises(ValueError, match="unknown log-domain kernel"):
+            warp_rnnt_amd.set_logdomain_kernel("fast")
+    finally:
+        warp_rnnt_amd.set_logdomain_kernel("auto")
     assert L.rnnt_amd_workspace_size_compact(4, 4 * 700 * 200, 700, 200) > L.rnnt_amd_workspace_size_compact(4, 4 * 700 * 200, 700, 64)
 
 

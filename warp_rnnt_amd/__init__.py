@@ -42,4 +42,16 @@ def lattice_route(route):
     finally:
         set_lattice(old)
 
+LOGDOMAIN_KERNELS = ("auto", "ws", "wd")
+
+
+def set_logdomain_kernel(kernel):
+    """Which kernel serves the log-domain arithmetic (``rnnt_amd_set_logdomain_kernel``): ``"auto"`` by shape, ``"ws"``
+    one workgroup per sweep, ``"wd"`` one workgroup per 64-column block.  Same bits either way: a tuning / test knob.
+    Process-wide, not thread-safe (like :func:`set_lattice`).  Returns the previous setting."""
+    if kernel not in LOGDOMAIN_KERNELS:
+        raise ValueError(f"unknown log-domain kernel {kernel!r}: expected one of {LOGDOMAIN_KERNELS}")
+    return LOGDOMAIN_KERNELS[load().rnnt_amd_set_logdomain_kernel(LOGDOMAIN_KERNELS.index(kernel))]
+
+
 __version__ = "0.1.0"

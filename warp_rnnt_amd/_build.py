@@ -11,8 +11,9 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libwarp_rnnt_amd.so")
-SOURCES = ["api.hip", "lattice.hip", "lattice_ws.hip", "lattice_pd.hip", "grads.hip", "prologue.hip", "expand.hip"]
-HEADERS = ["common.h", "kernels.h", os.path.join("..", "..", "include", "warp_rnnt_amd.h")]
+SOURCES = ["api.hip", "lattice.hip", "lattice_ws.hip", "lattice_wd.hip", "lattice_pd.hip", "grads.hip", "prologue.hip",
+           "expand.hip"]
+HEADERS = ["common.h", "kernels.h", "lattice_step.h", os.path.join("..", "..", "include", "warp_rnnt_amd.h")]
 ARCH = "gfx950"
 
 
@@ -56,7 +57,7 @@ VARIANTS = {
     "precise": ["-DRNNT_LATTICE_LOGDOMAIN", "-DRNNT_LATTICE_LEGACY", "-DRNNT_PRECISE_LIBM"],
     # hand-over waits that give up at once: every column block that catches up with its neighbour flags its sweep
     # for the log-domain kernel (the "producer lost" path, which never triggers otherwise)
-    "short_spin": ["-DRNNT_PD_SPIN_LIMIT=0"],
+    "short_spin": ["-DRNNT_PD_SPIN_LIMIT=0", "-DRNNT_WD_SPIN_LIMIT=0"],
 }
 
 

@@ -48,8 +48,13 @@ SYMBOLS = {
     "rnnt_amd_debug_gather_only": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i]),
     "rnnt_amd_set_lattice": (_i, [_i]),
     "rnnt_amd_get_lattice": (_i, []),
+    "rnnt_amd_set_logdomain_kernel": (_i, [_i]),
+    "rnnt_amd_get_logdomain_kernel": (_i, []),
     "rnnt_amd_version": (_i, []),
 }
+
+
+ABI_VERSION = 103   # rnnt_amd_version() of the library these argument lists belong to
 
 
 class RNNTStatusError(RuntimeError):
@@ -78,5 +83,10 @@ def load():
         fn = getattr(L, name)   # AttributeError if the library does not export a declared symbol
         fn.restype = res
         fn.argtypes = args
+    # the argument lists above are this version's: an older build of the library (a stale prebuilt .so, a
+    # WARP_RNNT_AMD_LIB variant built from older sources) would accept the calls and misread them
+    if L.rnnt_amd_version() != ABI_VERSION:
+        raise RuntimeError(f"{path} reports C-ABI version {L.rnnt_amd_version()}, this package binds version "
+                           f"{ABI_VERSION}: rebuild it (`python warp_rnnt_amd/_build.py`)")
     _lib = L
     return L

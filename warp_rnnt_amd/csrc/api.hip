@@ -36,7 +36,7 @@ size_t carve(void* base, int N, int T, int U, Workspace* w) {
     int* mismatch = reinterpret_cast<int*>(take((size_t)N * sizeof(int)));
     int* redo = reinterpret_cast<int*>(take(((size_t)N * 2 + 2) * sizeof(int)));   // flags, queue head, launch counter
     // (reserved by SHAPE, never by the current route: the size of a workspace must not depend on a setting)
-    unsigned long long* mail = reinterpret_cast<unsigned long long*>(take(pd_mail_bytes(N, T, U)));
+    unsigned long long* mail = reinterpret_cast<unsigned long long*>(take(lattice_mail_bytes(N, T, U)));
     if (w) *w = Workspace{alphas, betas, ws2, ll, mismatch, redo, mail};
     return off;
 }
@@ -53,11 +53,15 @@ bool dims_ok(int N, int T, int U) {
 
 extern "C" {
 
-int rnnt_amd_version(void) { return 102; }
+int rnnt_amd_version(void) { return 103; }
 
 int rnnt_amd_set_lattice(int route) { return set_lattice_route(route); }
 
 int rnnt_amd_get_lattice(void) { return lattice_route(); }
+
+int rnnt_amd_set_logdomain_kernel(int kernel) { return set_logdomain_kernel(kernel); }
+
+int rnnt_amd_get_logdomain_kernel(void) { return logdomain_kernel(); }
 
 size_t rnnt_amd_workspace_size(int N, int T, int U) {
     if (!dims_ok(N, T, U)) return 0;
@@ -200,7 +204,7 @@ size_t carve_compact(void* base, int N, int64_t STU, int Tmax, int Umax, Compact
     float* ll = reinterpret_cast<float*>(take((size_t)N * 4));
     int* mismatch = reinterpret_cast<int*>(take((size_t)N * 4));
     int* redo = reinterpret_cast<int*>(take(((size_t)N * 2 + 2) * sizeof(int)));
-    unsigned long long* mail = reinterpret_cast<unsigned long long*>(take(pd_mail_bytes(N, Tmax, Umax)));
+    unsigned long long* mail = reinterpret_cast<unsigned long long*>(take(lattice_mail_bytes(N, Tmax, Umax)));
     if (w) *w = CompactWorkspace{alphas, betas, ws2, ll, mismatch, redo, mail};
     return off + ALIGN;
 }

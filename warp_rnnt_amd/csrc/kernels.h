@@ -72,6 +72,26 @@ hipError_t launch_lattice_ws(hipStream_t stream, const LatticeArgs& a, int N);
 // a.mail of pd_mail_bytes(N,T,U) bytes); hipErrorNotSupported when they are missing
 hipError_t launch_lattice_pd(hipStream_t stream, const LatticeArgs& a, int N);
 size_t pd_mail_bytes(int N, int T, int U);
+// distributed log-domain variant (lattice_wd.hip; diagonal-major loader, padded or 64-bit compact; one workgroup per
+// 64-column block, any U); needs a.redo, a.queue and -- for U > 64 -- a.mail of wd_mail_bytes(N,T,U) bytes;
+// hipErrorNotSupported when they are missing.  Bit-identical to launch_lattice_ws.
+hipError_t launch_lattice_wd(hipStream_t stream, const LatticeArgs& a, int N);
+size_t wd_mail_bytes(int N, int T, int U);
+// what a workspace reserves for the hand-over rings of either kernel (a function of the shape only)
+inline size_t lattice_mail_bytes(int N, int T, int U) {
+    const size_t p = pd_mail_bytes(N, T, U), w = wd_mail_bytes(N, T, U);
+    return p > w ? p : w;
+}
+// In front of every launch of a kernel that hands boundary columns over through L2 rings (lattice_pd.hip owns the
+// per-device launch counter): clears n_flags words at `flags` (redo flags + queue head), stores the next value of the
+// launch counter at flags[n_flags] and zeroes ring_bytes (a multiple of 16) at `rings`.
+hipError_t launch_ring_prepare(hipStream_t stream, int* flags, int n_flags, void* rings, size_t ring_bytes);
+unsigned next_launch_epoch();     // host part of the launch epoch: random start, +1 per call
+// Which kernel serves the log-domain route where both can (same bits either way): 0 = by shape, 1 = single workgroup
+// per sweep (lattice_ws.hip), 2 = one workgroup per column block (lattice_wd.hip).  Initial value from the
+// environment variable RNNT_LOGDOMAIN_KERNEL=ws|wd.
+int logdomain_kernel();
+int set_logdomain_kernel(int k);  // returns the previous setting, or -1 for an unknown value
 hipError_t launch_grads(hipStream_t stream, const GradArgs& a, int N, int loader, int writer);
 
 // prologue / epilogue streaming kernels

@@ -439,6 +439,7 @@ __global__ void __launch_bounds__(MAXW * WAVE) k_lattice(const LatticeArgs a) {
     if ((grp << 3) + 8 <= pairs_total) { n = (grp << 3) + (in & 7); dir = in >> 3; }
     else { const unsigned r = b - (grp << 4); n = (grp << 3) + (r >> 1); dir = r & 1; }   // tail group
     if (a.beta_only && !dir) return;
+    if (a.redo && a.redo[2 * n + dir] == 0) return;   // launched behind a ring kernel: only the sweeps it flagged
     if (dir)
         sweep<LOADER, true, COMPACT>(a, n, mail, trash);
     else
@@ -485,43 +486,20 @@ bool pd_shape_supported(int T, int U) {
     return (U + WAVE - 1) / WAVE <= 8;     // the log-domain kernel behind it must be able to redo a sweep (U <= 512)
 }
 
-hipError_t launch_lattice(hipStream_t stream, const LatticeArgs& a, int N, int loader) {
-    if (N <= 0) return hipSuccess;
-#ifndef RNNT_LATTICE_LEGACY
-    if (loader == LOAD_SKEWED) {
-#ifndef RNNT_LATTICE_LOGDOMAIN
-        // Long lattices of small batches: probability-domain sweep, one workgroup per 64-column block
-        // (lattice_pd.hip), followed by the log-domain kernel for the (utterance, direction) pairs whose inputs it
-        // flagged -- normally none: those workgroups return at once.  Where it pays, measured on MI355X
-        // (tools/lattice_probe.py, us per alpha+beta sweep, probability domain / log domain):
-        //   N=16: T=1500 U=64 65/93, U=300 114/158, U=512 141/211; T=3000 U=500 (N=8) 200/376; T=700 U=100 53/60;
-        //         but T=400 U=100 40/40, T=150 U=40 20/16 (the hand-over lag between the column blocks and the extra
-        //         launches are only recovered on long sweeps);
-        //   T=1500 U=300: N=32 166/161, N=64 254/201 (its column blocks want a CU each).
-        //   (profiles/r02_lattice_probe.txt)
-        // U <= 512 because the log-domain kernel behind it must be able to redo a sweep.
-        // The route is a per-call setting (LatticeArgs::route <- rnnt_amd_set_lattice(); the environment variable
-        // RNNT_LATTICE=logdomain|pd only provides its initial value): ROUTE_LOGDOMAIN pins the reference's
-        // arithmetic, ROUTE_PD takes the probability-domain kernel wherever it is supported.
-        const int nA = (a.U + WAVE - 1) / WAVE;
-        // (compact layout: the native entry's 64-bit cell offsets; a.T / a.U are then the launch bounds Tmax / Umax)
-        const bool pd_ok = a.redo && a.queue && !a.offs32 && pd_shape_supported(a.T, a.U);
-        bool use_pd = pd_ok && (long long)2 * N * nA <= device_cus() && a.T >= 640 && a.T >= 2 * a.U;
-        if (a.route == ROUTE_LOGDOMAIN) use_pd = false;
-        if (a.route == ROUTE_PD) use_pd = pd_ok;
-        if (use_pd) {
-            const hipError_t e = launch_lattice_pd(stream, a, N);
-            if (e == hipSuccess) return launch_lattice_ws(stream, a, N);
-            if (e != hipErrorNotSupported) return e;
-        }
-#endif
-        // log-domain compute / I/O wave pairs (lattice_ws.hip); one pass covers U <= 512
-        LatticeArgs b = a;
-        b.redo = nullptr;
-        const hipError_t e = launch_lattice_ws(stream, b, N);
-        if (e != hipErrorNotSupported) return e;
-    }
-#endif
+namespace {
+int logdomain_kernel_from_env() {
+    const char* v = getenv("RNNT_LOGDOMAIN_KERNEL");
+    if (v && v[0] == 'w' && v[1] == 's') return 1;
+    if (v && v[0] == 'w' && v[1] == 'd') return 2;
+    return 0;
+}
+std::atomic<int>& logdomain_kernel_setting() {
+    static std::atomic<int> r{logdomain_kernel_from_env()};
+    return r;
+}
+
+// the single-role kernel: one workgroup per sweep, 1024-column stripes, every loader; honours a.redo
+hipError_t launch_single(hipStream_t stream, const LatticeArgs& a, int N, int loader) {
     int waves = (a.U + WAVE - 1) / WAVE;
     waves = waves < 1 ? 1 : (waves > MAXW ? MAXW : waves);
     const dim3 grid(2 * N), block(waves * WAVE);
@@ -536,6 +514,70 @@ hipError_t launch_lattice(hipStream_t stream, const LatticeArgs& a, int N, int l
         default:             k_lattice<LOAD_DENSE, false><<<grid, block, 0, stream>>>(a); break;
     }
     return hipGetLastError();
+}
+}  // namespace
+
+int logdomain_kernel() { return logdomain_kernel_setting().load(std::memory_order_relaxed); }
+
+int set_logdomain_kernel(int k) {
+    if (k < 0 || k > 2) return -1;
+    return logdomain_kernel_setting().exchange(k, std::memory_order_relaxed);
+}
+
+hipError_t launch_lattice(hipStream_t stream, const LatticeArgs& a, int N, int loader) {
+    if (N <= 0) return hipSuccess;
+    LatticeArgs plain = a;          // for the kernels that sweep everything: no redo flags to look at
+    plain.redo = nullptr;
+#ifndef RNNT_LATTICE_LEGACY
+    if (loader == LOAD_SKEWED) {
+        const int nA = (a.U + WAVE - 1) / WAVE;
+        // the kernels that hand boundary columns over through L2 rings need the flags, the work queue and the rings
+        // (compact layout: the native entry's 64-bit cell offsets; a.T / a.U are then the launch bounds Tmax / Umax)
+        const bool ring_ok = a.redo && a.queue && !a.offs32 && (nA == 1 || a.mail);
+        // ... and behind them the single-workgroup log-domain kernel for the sweeps they flagged (normally none:
+        // its workgroups read one flag and return)
+        auto redo_behind = [&]() {
+            const hipError_t e = launch_lattice_ws(stream, a, N);
+            return e != hipErrorNotSupported ? e : launch_single(stream, a, N, loader);
+        };
+#ifndef RNNT_LATTICE_LOGDOMAIN
+        // Long lattices of small batches: probability-domain sweep, one workgroup per 64-column block
+        // (lattice_pd.hip).  Where it pays, measured on MI355X (tools/lattice_probe.py, us per alpha+beta sweep,
+        // probability domain / single-workgroup log domain):
+        //   N=16: T=1500 U=64 65/93, U=300 114/158, U=512 141/211; T=3000 U=500 (N=8) 200/376; T=700 U=100 53/60;
+        //         but T=400 U=100 40/40, T=150 U=40 20/16 (the hand-over lag between the column blocks and the extra
+        //         launches are only recovered on long sweeps);
+        //   T=1500 U=300: N=32 166/161, N=64 254/201 (its column blocks want a CU each).
+        // U <= 512 because the log-domain kernel behind it must be able to redo a sweep.
+        // The route is a per-call setting (LatticeArgs::route <- rnnt_amd_set_lattice(); the environment variable
+        // RNNT_LATTICE=logdomain|pd only provides its initial value): ROUTE_LOGDOMAIN pins the reference's
+        // arithmetic, ROUTE_PD takes the probability-domain kernel wherever it is supported.
+        const bool pd_ok = ring_ok && pd_shape_supported(a.T, a.U);
+        bool use_pd = pd_ok && (long long)2 * N * nA <= device_cus() && a.T >= 640 && a.T >= 2 * a.U;
+        if (a.route == ROUTE_LOGDOMAIN) use_pd = false;
+        if (a.route == ROUTE_PD) use_pd = pd_ok;
+        if (use_pd) {
+            const hipError_t e = launch_lattice_pd(stream, a, N);
+            if (e == hipSuccess) return redo_behind();
+            if (e != hipErrorNotSupported) return e;
+        }
+#endif
+        // Log domain.  Two kernels, the same bits: lattice_ws.hip (all column blocks of a sweep in one workgroup; one
+        // pass covers U <= 512) and lattice_wd.hip (one workgroup per column block, boundary columns through L2).
+        const int kern = logdomain_kernel();
+        bool use_wd = ring_ok && nA >= 2;
+        if (kern == 1) use_wd = false;
+        if (kern == 2) use_wd = ring_ok;
+        if (use_wd) {
+            const hipError_t e = launch_lattice_wd(stream, a, N);
+            if (e == hipSuccess) return redo_behind();
+            if (e != hipErrorNotSupported) return e;
+        }
+        const hipError_t e = launch_lattice_ws(stream, plain, N);
+        if (e != hipErrorNotSupported) return e;
+    }
+#endif
+    return launch_single(stream, plain, N, loader);
 }
 
 }  // namespace rnnt

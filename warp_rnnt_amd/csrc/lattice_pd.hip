@@ -713,6 +713,22 @@ size_t pd_mail_bytes(int N, int T, int U) {
     return bytes;
 }
 
+unsigned next_launch_epoch() {
+    // granules of earlier launches (same buffer) never validate.  Random start so that a recycled allocation of
+    // another process does not either; the device-side counter (k_prepare) is added in the kernel.
+    static std::atomic<unsigned> epoch{std::random_device{}()};
+    return epoch.fetch_add(1, std::memory_order_relaxed) + 1;
+}
+
+hipError_t launch_ring_prepare(hipStream_t stream, int* flags, int n_flags, void* rings, size_t ring_bytes) {
+    // the flags (2N ints) and the queue head are contiguous in the workspace (api.hip: carve).  One tiny kernel:
+    // hipMemsetAsync of these few bytes becomes two fill kernels of ~5 us each.
+    const size_t mail_vec = ring_bytes / 16;
+    const unsigned prep_blocks = (unsigned)std::min<size_t>(512, std::max<size_t>(1, mail_vec / (256 * 8)));
+    pd::k_prepare<<<prep_blocks, 256, 0, stream>>>(flags, n_flags, reinterpret_cast<uint4*>(rings), mail_vec);
+    return hipGetLastError();
+}
+
 // Needs a.redo, a.queue = a.redo + 2N with the launch counter behind it (and a.mail when U > 64); zeroes redo and
 // the queue head itself.
 hipError_t launch_lattice_pd(hipStream_t stream, const LatticeArgs& a0, int N) {
@@ -720,18 +736,11 @@ hipError_t launch_lattice_pd(hipStream_t stream, const LatticeArgs& a0, int N) {
     const int nA = (a0.U + WAVE - 1) / WAVE;
     if (!a0.redo || !a0.queue || (nA > 1 && !a0.mail)) return hipErrorNotSupported;
     if ((long long)2 * N * nA >= (1ll << 31)) return hipErrorNotSupported;
-    // launch epoch: granules of earlier launches (same buffer) never validate.  Random start so that a recycled
-    // allocation of another process does not either; the device-side counter (k_prepare) is added in the kernel.
-    static std::atomic<unsigned> epoch{std::random_device{}()};
     LatticeArgs a = a0;
-    a.epoch = epoch.fetch_add(1, std::memory_order_relaxed) + 1;
+    a.epoch = next_launch_epoch();
     a.mail_blocks = (int)pd_mail_blocks(a.T, a.U);
-    // redo (2N ints) and the queue head are contiguous in the workspace (api.hip: carve).  One tiny kernel:
-    // hipMemsetAsync of these few bytes becomes two fill kernels of ~5 us each.
-    const size_t mail_vec = nA > 1 ? (size_t)2 * N * (nA - 1) * a.mail_blocks * pd::GPITCH * sizeof(pd::u64) / 16 : 0;
-    const unsigned prep_blocks = (unsigned)std::min<size_t>(512, std::max<size_t>(1, mail_vec / (256 * 8)));
-    pd::k_prepare<<<prep_blocks, 256, 0, stream>>>(a.redo, 2 * N + 1, reinterpret_cast<uint4*>(a.mail), mail_vec);
-    hipError_t e = hipGetLastError();
+    const size_t ring_bytes = nA > 1 ? (size_t)2 * N * (nA - 1) * a.mail_blocks * pd::GPITCH * sizeof(pd::u64) : 0;
+    hipError_t e = launch_ring_prepare(stream, a.redo, 2 * N + 1, a.mail, ring_bytes);
     if (e != hipSuccess) return e;
     const dim3 grid(2 * N * nA), block(5 * WAVE);
     // (Forcing one workgroup per CU -- by claiming more than half of a CU's LDS -- was measured: no difference at

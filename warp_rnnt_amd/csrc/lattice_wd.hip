@@ -1,0 +1,486 @@
+// Distributed log-domain alpha / beta lattice sweep for MI355X (gfx950), diagonal-major layout (padded or compact):
+// the reference's arithmetic -- one fp32 lse per cell, core_gather.cu:22-35,106-126,207-227 -- with ONE WORKGROUP PER
+// 64-COLUMN BLOCK of a sweep.
+//
+// The step is lattice_ws.hip's, literally (lattice_step.h: same instructions on the chain, same bits): lanes are
+// lattice columns, blocks of K = 8 diagonals, one s_barrier per block, a COMPUTE wave that touches only registers and
+// LDS.  What changes is everything around it.
+//
+// 1. WHERE the column blocks run.  In lattice_ws.hip they share a workgroup, hence a CU, and all meet at every
+//    barrier.  Here a column block is a workgroup of its own (three waves), wherever the dispatcher puts it, and the
+//    boundary column travels through L2 the way lattice_pd.hip's does:
+//      * ring: one 8-byte granule {fp32 value, 32-bit tag} per diagonal and (sweep, boundary); the producer's storer
+//        wave publishes the 8 granules of a block with one agent-scope (sc1) store instruction the interval after the
+//        compute wave produced them; tag = launch epoch ^ hash(ring) ^ hash(diagonal), never 0, and the rings are
+//        zeroed in front of every launch (launch_ring_prepare): a granule validates only if THIS launch wrote it;
+//      * the consumer's loader wave fetches the granules of a block DLOAD intervals ahead (LDS-DMA, like the pairs),
+//        checks the tags when the block is due, and only if the producer is not there yet polls (after letting it get
+//        LAG blocks further ahead, so that the following look-ahead fetches hit).  No flag, no fence, no back-pressure:
+//        the ring is as long as the sweep;
+//      * work items (column block, sweep) come from an atomic counter in column-block-major order: whoever holds item
+//        i knows that its left neighbour, item i - 2N, is held by a workgroup that is running or done -- no assumption
+//        about dispatch order or residency, any batch size;
+//      * every wait is bounded; a timeout flags the sweep for the single-workgroup kernel launched behind (which
+//        returns at once otherwise) instead of hanging.
+// 2. The memory side has NO data-dependent control flow around memory instructions and no compiler-counted loads.
+//    Measured (profiles/r04_wd_trace_*.txt, ISA): with "guarded" steps at the ends of a column block's life (memory
+//    instructions under conditions) the waitcnt pass assumes the worst at every join and each such interval waits for
+//    everything in flight -- ~1.5 us instead of 0.4 -- and because the heads of a sweep's column blocks run one
+//    after the other that was ~20 us per boundary, in lattice_ws.hip too.  Here:
+//      * LOADER wave: the (blank,label) pairs of a block arrive by LDS-DMA (four `buffer_load_dwordx4 ... lds`: two
+//        diagonals of 64 pairs each), the neighbour's granules by a fifth; every interval issues all five (an
+//        out-of-range offset where there is nothing to fetch: zeros land), waits with ONE hand-counted
+//        `s_waitcnt vmcnt` and never holds a byte of it in a register; polls are inline assembly that drains the
+//        queue itself;
+//      * STORER wave: values LDS -> HBM one block behind (per-lane predicate, dropped by the buffer range check) and the
+//        publication of the boundary column; stores only, it never waits for memory.
+// 3. Instruction fetch.  A wave runs a 200-instruction block of straight-line code cold in ~2.4 us (the trace: first
+//    block of each variant), and a column block's first blocks are on the critical path of the whole sweep.  So the
+//    block exists ONCE per variant (compute_block_ip: in-place prefetch instead of two register buffers and a loop
+//    unrolled twice) and the storer wave -- idle for the first intervals anyway -- runs the compute loop "dry" for
+//    one block per variant before it takes up its own work: same instructions, same addresses, a warm instruction
+//    cache when the compute wave gets there.
+// Values handed over are the compute wave's own fp32 X registers, so the results are bit-identical to
+// lattice_ws.hip's whatever the placement and timing (tests/test_gpu_wd.py).
+#include <algorithm>
+#include <type_traits>
+
+#include "common.h"
+#include "kernels.h"
+#include "lattice_step.h"
+
+namespace rnnt {
+
+namespace wd {
+
+using ws::K;
+using ws::f32x2;
+using ws::block_barrier;
+using ws::compute_block_ip;
+using ws::RSRC_WORD3;
+using ws::OOB;
+using ws::TRASH;
+
+#ifndef RNNT_WD_DLOAD
+#define RNNT_WD_DLOAD 2
+#endif
+constexpr int DLOAD = RNNT_WD_DLOAD;   // the loader fetches a block this many intervals before the compute wave reads it
+constexpr int PSLOTS = DLOAD + 4;      // LDS ring of pair blocks: fetched DLOAD intervals before the compute wave's first
+                                       // read, kept until the storer has taken the last column's label log-probs (3 later)
+constexpr int VSLOTS = 2;              // LDS ring of value blocks
+
+constexpr int MIN_SLOTS = 8;           // ... of incoming ones (granules as the neighbour published them); >= DLOAD + 2
+static_assert(DLOAD >= 2 && DLOAD + 2 <= MIN_SLOTS, "ring depths");
+#ifndef RNNT_WD_SPIN_LIMIT
+#define RNNT_WD_SPIN_LIMIT (1 << 21)
+#endif
+constexpr int SPIN_LIMIT = RNNT_WD_SPIN_LIMIT;   // polls before a hand-over is declared lost (seconds)
+#ifndef RNNT_WD_LAG
+#define RNNT_WD_LAG 1
+#endif
+constexpr int LAG = RNNT_WD_LAG; // blocks a column block lets its left neighbour get ahead once it has caught up with it
+
+typedef unsigned long long u64;
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+struct alignas(16) Smem {
+    f32x2 pairs[PSLOTS][K][WAVE];     // [slot][diagonal][position]: the LDS-DMA's landing zone (lane-linear)
+    float vals[VSLOTS][K][WAVE];
+    u64 mail_raw[MIN_SLOTS][K];       // left neighbour's granules for a block (diagonals d0-1 .. d0+K-2) as they landed
+    float mail_vals[MIN_SLOTS][K];    // ... their values, once the loader has checked the tags
+    float trash[TRASH];
+};
+
+__device__ __forceinline__ unsigned ring_tag(unsigned epoch, unsigned ring) { return epoch ^ (ring * 0x85EBCA6Bu); }
+__device__ __forceinline__ unsigned diag_tag(unsigned ring_epoch, int d) {
+    const unsigned t = ring_epoch ^ ((unsigned)(d + 1) * 0x9E3779B1u);
+    return t ? t : 1u;
+}
+
+struct Item { int n, dir, cb; };
+
+__host__ __device__ inline size_t trace_slots(int T, int U) { return (size_t)(T + U - 1) / K + 24; }
+
+// Granules per ring.  The granule of diagonal d sits at index d + 1, so that the eight a consumer block needs
+// (diagonals m*K-1 .. m*K+K-2) are one aligned 64-byte group; the last index is a pad that publications of blocks which
+// do not exist go to.
+__host__ __device__ inline size_t ring_pitch(int T, int U) { return ((size_t)(T + U - 1 + K - 1) / K + 2) * K; }
+
+// 128-bit buffer descriptor in SGPRs for the inline-assembly LDS-DMA (raw buffer, 32-bit data format)
+__device__ __forceinline__ i32x4 make_rsrc(const void* p, unsigned bytes) {
+    const u64 a = (u64)p;
+    i32x4 r;
+    r.x = __builtin_amdgcn_readfirstlane((int)(unsigned)a);
+    r.y = __builtin_amdgcn_readfirstlane((int)((unsigned)(a >> 32) & 0xffffu));
+    r.z = __builtin_amdgcn_readfirstlane((int)bytes);
+    r.w = __builtin_amdgcn_readfirstlane(RSRC_WORD3);
+    return r;
+}
+// One LDS-DMA piece: lane l's 16 bytes at (descriptor base + voff + soff) land at LDS byte address lds + 16 l; a voff
+// beyond the descriptor's range lands zeros.  M0 (the LDS base) is written in the statement that reads it and left
+// there: nothing the compiler generates for these waves reads M0.
+__device__ __forceinline__ void dma16(const int voff, const i32x4 rs, const int soff, unsigned lds) {
+    lds = __builtin_amdgcn_readfirstlane(lds);
+    asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds" ::"v"(voff), "s"(rs), "s"(soff), "s"(lds) : "memory");
+}
+__device__ __forceinline__ void dma16_agent(const int voff, const i32x4 rs, unsigned lds) {   // agent scope (sc1)
+    lds = __builtin_amdgcn_readfirstlane(lds);
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen sc1 lds" ::"v"(voff), "s"(rs), "s"(lds) : "memory");
+}
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+__device__ __forceinline__ unsigned lds_addr(const void* p) {
+    return __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) const char*)p);
+}
+
+template <bool BETA, bool COMPACT, bool HAS_LEFT, bool HAS_RIGHT>
+__device__ __forceinline__ void sweep(const LatticeArgs& a, const Item it, const UttLens len, const int nA, Smem& sm,
+                                      int* wg_bad) {
+    const int n = it.n, idx = it.cb;
+    const int Tn = len.Tn, Un = len.Un;
+    const int T = COMPACT ? Tn : a.T, U = COMPACT ? Un : a.U;
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // 0 compute, 1 loader, 2 storer
+    const size_t nbase = COMPACT ? (size_t)a.offs[n] : (size_t)n * T * U;
+    float* out = (BETA ? a.betas : a.alphas) + nbase;
+    if (Un == 1) {   // no labels: prefix / suffix sums by one wave of the first column block's workgroup
+        if (idx == 0 && role == 0) {
+            const float2* lp2 = reinterpret_cast<const float2*>(a.lp) + nbase;
+            const float total = single_column_scan<BETA>(Tn, out, U, lane, [&](int t) { return lp2[(size_t)t * U].x; });
+            if (!BETA && lane == 0) a.ll[n] = total;
+        }
+        return;
+    }
+    const int ndiag = Tn + Un - 1;
+    const float NEG_INF = -__builtin_inff();
+
+    const int wave_c = WAVE * idx;                    // first sweep column of this column block
+    const int ucol = wave_c + lane;                   // column in sweep coordinates
+    const bool colvalid = ucol < Un;
+    const int u = BETA ? (Un - 1 - ucol) : ucol;
+    const int uc = min(max(u, 0), U - 1);
+    const int ucol_chk = colvalid ? ucol : 0x40000000;
+    const int nwa = (Un + WAVE - 1) / WAVE;           // column blocks with a live column
+    const int lo = wave_c / K;
+    const int hi = (min(ndiag, Tn + wave_c + WAVE) + K - 1) / K;
+    if (idx >= nwa || lo >= hi) return;               // nothing to sweep here (uniform)
+    // blocks for which the left neighbour publishes a boundary column this block still needs
+    const int hi_left = HAS_LEFT ? (min(ndiag, Tn + wave_c) + K - 1) / K : 0;
+    // Local time p: one interval per block of K diagonals, one s_barrier per interval, the same [p0, p1) for every wave.
+    //   loader   interval p: pairs(p) and the neighbour's block p have landed (checked); fetches both for p+DLOAD
+    //   compute  interval p: block p-2 (reads pairs(p-1) for the block after it as it goes)
+    //   storer   interval p: values and boundary column of block p-3
+    const int p0 = lo - DLOAD, p1 = hi + 3;
+    // the window of memory columns the pairs of this column block come from, and where a lane's column sits in it
+    const int cwin = BETA ? max(0, Un - WAVE - wave_c) : wave_c;
+    const int pos = BETA ? max(0, Un - 1 - ucol - cwin) : lane;
+    // hand-over rings in global memory: one per (sweep, column-block boundary)
+    const size_t sweep_id = (size_t)2 * n + (BETA ? 1 : 0);
+    const size_t pitch = ring_pitch(a.T, a.U);
+    u64* ring_in = HAS_LEFT ? a.mail + (sweep_id * (nA - 1) + (idx - 1)) * pitch : nullptr;
+    u64* ring_out = HAS_RIGHT ? a.mail + (sweep_id * (nA - 1) + idx) * pitch : nullptr;
+    const unsigned tag_in = ring_tag(a.epoch, (unsigned)(sweep_id * (nA - 1) + (idx - 1)));
+    const unsigned tag_out = ring_tag(a.epoch, (unsigned)(sweep_id * (nA - 1) + idx));
+    (void)ring_in; (void)ring_out; (void)tag_in; (void)tag_out;
+    // row (forward diagonal mod T) of the first diagonal of block `lo`
+    const int dF0 = BETA ? (ndiag - 1 - lo * K) : lo * K;
+    const int row0 = ((dF0 % T) + T) % T;
+#ifdef RNNT_WD_STATS       // diagnostics build (tools/wd_trace.py): a (sweep, column block, interval) table of s_memrealtime
+                           // stamps behind the rings, 8 words per interval: 0/1 compute wave enters / leaves the block of
+                           // the interval, 2/3 loader enters / leaves its step, 4 ticks it waited for the neighbour,
+                           // 5/6 storer enters / leaves.  Costs a few per cent; never part of the product build.
+    u64* const trace = a.mail + (size_t)(gridDim.x / nA) * (nA - 1) * ring_pitch(a.T, a.U) +
+                       (((size_t)2 * it.n + it.dir) * nA + idx) * (size_t)trace_slots(a.T, a.U) * 8;
+#define RNNT_WD_STAMP(p_, word) do { if (lane == 0) trace[8 * ((p_) + 8) + (word)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define RNNT_WD_STAMP(p_, word) do { } while (0)
+#endif
+
+    if (role == 1) {
+        // ------------------------------ loader wave ------------------------------
+        const i32x4 rs_lp = make_rsrc(reinterpret_cast<const float2*>(a.lp) + nbase, (unsigned)((size_t)T * U * 8));
+        const i32x4 rs_ring = make_rsrc(ring_in, HAS_LEFT ? (unsigned)(pitch * 8) : 0u);
+        const unsigned lds_pairs = lds_addr(&sm.pairs[0][0][0]);
+        const unsigned lds_raw = lds_addr(&sm.mail_raw[0][0]);
+        const int rowb = U * 8;
+        const int half = lane >> 5;                            // lanes 0-31 fetch diagonal 2j of a block, 32-63 diagonal 2j+1
+        const int colb = (cwin + 2 * (lane & 31)) * 8;         // 16 bytes = two columns
+        int row_ld = row0;                                     // row of the first diagonal of the next block to fetch
+        int slot_ld = 0;                                       // its slot in the LDS ring (block lo = slot 0)
+        constexpr int NDMA = 4 + (HAS_LEFT ? 1 : 0);           // pieces per interval, always all of them
+        // per-lane part of a piece's offset while the K rows of a block do not wrap around the plane (the rule): column
+        // + this lane's diagonal relative to the block's lowest row, which goes into the scalar offset
+        int voff_j[K / 2];
+#pragma unroll
+        for (int j = 0; j < K / 2; ++j) voff_j[j] = colb + (BETA ? (K - 1) - (2 * j + half) : (2 * j + half)) * rowb;
+        // a poll of the neighbour's block m: lanes 0..K-1 load their granule, load + wait in ONE piece of assembly
+        // that leaves the queue empty
+        const int mlane = lane < K ? lane : K - 1;
+        auto mail_poll = [&](const int m) {
+            u64 g;
+            asm volatile("global_load_dwordx2 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(g) : "v"(ring_in + (m * K + mlane)) : "memory");
+            return g;
+        };
+        auto mail_valid = [&](const int m, const u64 g) {
+            const bool ok = (unsigned)(g >> 32) == diag_tag(tag_in, m * K - 1 + mlane);
+            return __builtin_amdgcn_ballot_w64(!ok) == 0;
+        };
+        bool lost = false;     // a wait has timed out: the sweep is flagged for the kernel behind, the rest of it
+                               // runs on whatever the ring holds without waiting again
+        auto mail_wait = [&](const int m) {                // poll until block m of the neighbour is there
+            for (int spins = 0;; ++spins) {
+                const u64 g = mail_poll(m);
+                if (lost || mail_valid(m, g)) return g;
+                if (spins >= SPIN_LIMIT) { atomicOr(wg_bad, 2); lost = true; return g; }
+                __builtin_amdgcn_s_sleep(2);
+            }
+        };
+        for (int p = p0; p < p1; ++p) {
+            RNNT_WD_STAMP(p, 2);
+            wait_vmcnt<NDMA * (DLOAD - 1)>();                  // everything fetched DLOAD intervals ago has landed
+            if constexpr (HAS_LEFT) {
+                const int m = p;
+                if (m >= lo && m < hi_left) {
+                    u64 g = sm.mail_raw[m & (MIN_SLOTS - 1)][mlane];
+                    if (!mail_valid(m, g)) {
+                        // fetched DLOAD intervals ago and the producer had not got there: this column block has
+                        // caught up with its neighbour.  Let the neighbour get LAG blocks ahead (or finish) before
+                        // going on, so that the look-ahead fetches of the following blocks find their data.
+#ifdef RNNT_WD_STATS
+                        const u64 t_wait = __builtin_amdgcn_s_memrealtime();
+#endif
+                        if (LAG > 0 && m > lo) mail_wait(min(m + LAG, hi_left - 1));   // (the first block: at once)
+                        g = mail_wait(m);
+                        // what was fetched ahead for the following blocks was fetched before this one existed: again
+                        // (older than anything the counted waits below wait for, so they only get more conservative)
+#pragma unroll
+                        for (int q = 1; q < DLOAD; ++q) {
+                            const int mq = min(m + q, hi_left - 1);
+                            if (lane < K / 2) dma16_agent(mq * (K * 8) + lane * 16, rs_ring, lds_raw + (unsigned)((m + q) & (MIN_SLOTS - 1)) * (K * 8));
+                        }
+#ifdef RNNT_WD_STATS
+                        if (lane == 0) trace[8 * (p + 8) + 4] = __builtin_amdgcn_s_memrealtime() - t_wait;
+#endif
+                    }
+                    if (lane < K) sm.mail_vals[m & (MIN_SLOTS - 1)][lane] = __builtin_bit_cast(float, (unsigned)g);
+                }
+            }
+            {
+                const int pl = p + DLOAD;
+                const bool live = pl >= lo && pl < hi;
+                const unsigned dst = lds_pairs + (unsigned)slot_ld * (unsigned)(K * WAVE * 8);
+                if (BETA ? row_ld >= K - 1 : row_ld + K <= T) {
+                    const int soff = (BETA ? row_ld - (K - 1) : row_ld) * rowb;
+#pragma unroll
+                    for (int j = 0; j < K / 2; ++j) dma16(live ? voff_j[j] : OOB, rs_lp, soff, dst + j * (2 * WAVE * 8));
+                } else {                                       // the block's rows wrap (once per sweep; T < K: several times)
+#pragma unroll
+                    for (int j = 0; j < K / 2; ++j) {
+                        int r = BETA ? row_ld - (2 * j + half) : row_ld + (2 * j + half);
+                        r = ((r % T) + T) % T;
+                        dma16(live ? r * rowb + colb : OOB, rs_lp, 0, dst + j * (2 * WAVE * 8));
+                    }
+                }
+                if (live) {
+                    row_ld = BETA ? row_ld - K : row_ld + K;
+                    if (T >= K) { if (BETA) { if (row_ld < 0) row_ld += T; } else { if (row_ld >= T) row_ld -= T; } }
+                    else row_ld = ((row_ld % T) + T) % T;
+                    slot_ld = slot_ld + 1 == PSLOTS ? 0 : slot_ld + 1;
+                }
+            }
+            if constexpr (HAS_LEFT) {
+                const int ml = p + DLOAD;
+                const int mm = (ml >= lo && ml < hi_left) ? ml : lo;   // (always a block of the ring: the piece is
+                                                                        //  issued regardless, its bytes not looked at)
+                if (lane < K / 2) dma16_agent(mm * (K * 8) + lane * 16, rs_ring, lds_raw + (unsigned)(ml & (MIN_SLOTS - 1)) * (K * 8));
+            }
+            RNNT_WD_STAMP(p, 3);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (its own LDS writes; NOT the pieces in flight)
+            __builtin_amdgcn_s_barrier();
+        }
+        return;
+    }
+
+    if (role != 1) {
+        // ------------------------------ compute wave (and the storer's dry run) ------------------------------
+        // The storer wave runs this loop "dry" before it takes up its own work: one block per variant this column block
+        // will run, on whatever the registers and LDS hold, no barrier -- for the instruction cache (header, point 3).
+        // Everything it writes (vals) is written again by the real blocks before anybody reads it: no real
+        // block starts before the storer has reached the first barriers.
+        const bool dry = role == 2;
+        float Y = (ucol == 0) ? 0.0f : NEG_INF;
+        float X = NEG_INF;
+        f32x2 cur[K];
+        float seed[K];
+        // Blocks [lo, head_end) and [full_end, hi) have lanes that start or finish inside them (predicated variant),
+        // [head_end, full_end) have every lane that owns a column live throughout (lanes beyond the last column run
+        // the unpredicated code too: their values only travel right, their stores are dropped).
+        const int fb0 = max(lo, (min(wave_c + WAVE - 1, Un - 1) + K - 1) / K);   // d0 >= the last column's first diagonal
+        const int fb1 = min(hi, (wave_c + Tn) / K);                              // d0 + K <= the first column's end
+        int lb, head_end, full_end, tail_end;
+        if (dry) {
+            // pseudo blocks: -2 in the predicated variant (a first column block goes straight into it at launch:
+            // warming it here would only delay the first barrier), -1 in the unpredicated one (needed K blocks later)
+            lb = idx > 0 ? -2 : -1;
+            head_end = -1; full_end = 0; tail_end = 0;
+#pragma unroll
+            for (int k = 0; k < K; ++k) { cur[k] = f32x2{-1.0f, -2.0f}; seed[k] = -3.0f; }
+        } else {
+            // block lb is computed during interval lb + 2: its pairs and the neighbour's block have landed and are
+            // checked by the end of interval lb
+            for (int t = p0; t < lo + 1; ++t) block_barrier();
+            const f32x2* src = &sm.pairs[0][0][pos];
+#pragma unroll
+            for (int k = 0; k < K; ++k) { cur[k] = src[k * WAVE]; seed[k] = HAS_LEFT ? sm.mail_vals[lo & (MIN_SLOTS - 1)][k] : NEG_INF; }
+            block_barrier();
+            lb = lo;
+            head_end = fb0 < fb1 ? fb0 : hi; full_end = fb0 < fb1 ? fb1 : head_end; tail_end = hi;
+        }
+        int slot = 0;                                          // LDS slot of block lb's pairs (block lo = slot 0)
+        const unsigned pairs0 = (unsigned)(size_t)(__attribute__((address_space(3))) const char*)&sm.pairs[0][0][pos];
+        const unsigned seeds0 = (unsigned)(size_t)(__attribute__((address_space(3))) const char*)&sm.mail_vals[0][0];
+        auto one_block = [&](auto masked_c) {
+            constexpr bool MASKED = decltype(masked_c)::value;
+            const int d0 = lb * K;
+            RNNT_WD_STAMP(lb + 2, 0);
+            slot = slot + 1 == PSLOTS ? 0 : slot + 1;          // now the NEXT block's slot: its pairs landed an interval ago
+            const unsigned nsrc = pairs0 + (unsigned)slot * (unsigned)(K * WAVE * 8);
+            const unsigned nseed = seeds0 + (unsigned)((lb + 1) & (MIN_SLOTS - 1)) * (K * 4);
+            float* vslot = &sm.vals[lb & (VSLOTS - 1)][0][lane];
+            // (no mailbox write on this wave: the storer rebuilds the boundary column from the values)
+            compute_block_ip<BETA, MASKED, false, HAS_LEFT>(cur, seed, nsrc, nseed, Y, X, d0, ucol_chk, Tn, vslot, nullptr);
+            RNNT_WD_STAMP(lb + 2, 1);
+            if (!dry) block_barrier();                         // (its lgkmcnt(0) also retires the in-place reloads)
+        };
+        // head, steady state, tail: the predicated loop exists once (outer loop of two rounds, not unrolled)
+#pragma nounroll
+        for (int round = 0; round < 2; ++round) {
+            const int mend = round == 0 ? head_end : tail_end;
+#pragma nounroll
+            for (; lb < mend; ++lb) one_block(std::true_type{});
+            if (round == 0) {
+#pragma nounroll
+                for (; lb < full_end; ++lb) one_block(std::false_type{});
+            }
+        }
+        if (!dry) {
+            for (int t = hi + 2; t < p1; ++t) block_barrier();
+            if constexpr (!BETA) {
+                // Y of a finished lane is frozen at alpha + lpB of its last live cell (core_gather.cu:339)
+                if (ucol == Un - 1) a.ll[n] = Y;
+            }
+            return;
+        }
+    }
+
+    // ------------------------------ storer wave ------------------------------
+    {
+        const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(out, 0, T * U * 4, RSRC_WORD3);
+        const int voff_out = colvalid ? uc * 4 : OOB;
+        const int rowb = U * 4;
+        int row_st = row0;
+        int slot_st = 0;                                       // LDS slot of block ps's pairs (block lo = slot 0)
+        for (int p = p0; p < p1; ++p) {
+            const int ps = p - 3;
+            const bool ps_live = ps >= lo && ps < hi;
+            RNNT_WD_STAMP(p, 5);
+            if constexpr (HAS_RIGHT) {
+                // (a block that does not exist goes to the ring's pad granule, which nobody reads; eight lanes store --
+                // an agent-scope store is one fabric write per lane)
+                if (lane < K) {
+                    const int d = ps * K + lane;
+                    const size_t at = ps_live ? (size_t)(d + 1) : pitch - 1;
+                    // what the compute wave's lane 63 handed to its DPP shift after diagonal d: its value (beta), its
+                    // value + the label log-prob of its cell (alpha) -- the same fp32 addition, the same bits.  (Where
+                    // lane 63 is not live the result is meaningless and no live cell of the neighbour reads it.)
+                    float x = sm.vals[ps & (VSLOTS - 1)][lane][WAVE - 1];
+                    if constexpr (!BETA) x += sm.pairs[slot_st][lane][WAVE - 1].y;   // (still in the ring: PSLOTS)
+                    const u64 g = ((u64)diag_tag(tag_out, d) << 32) | __builtin_bit_cast(unsigned, x);
+                    __hip_atomic_store(ring_out + at, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            const float* src = &sm.vals[ps & (VSLOTS - 1)][0][lane];
+            const int d0 = ps * K;
+            const int vo = ps_live ? voff_out : OOB;
+            int r = row_st;
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                const bool live = (unsigned)(d0 + k - ucol_chk) < (unsigned)Tn;
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, src[k * WAVE]), rs_out, live ? vo : OOB,
+                                                      r * rowb, 0);
+                r = BETA ? (r == 0 ? T - 1 : r - 1) : (r + 1 == T ? 0 : r + 1);
+            }
+            if (ps_live) { row_st = r; slot_st = slot_st + 1 == PSLOTS ? 0 : slot_st + 1; }
+            RNNT_WD_STAMP(p, 6);
+            __builtin_amdgcn_s_barrier();                      // (its LDS reads are complete: the stores needed them)
+        }
+    }
+}
+
+template <bool COMPACT>
+__global__ void __launch_bounds__(3 * WAVE) k_lattice_wd(LatticeArgs a, const int nA) {
+    __shared__ Smem sm;
+    __shared__ int wg_bad, s_item;
+    // launch epoch = host counter (constant across the replays of a captured graph) + the library's per-device launch
+    // counter (queue[1], bumped by the preparation kernel in front of every launch, replayed or not)
+    a.epoch += (unsigned)a.queue[1];
+    if (threadIdx.x == 0) { s_item = atomicAdd(a.queue, 1); wg_bad = 0; }
+    __syncthreads();
+    const int sweeps = gridDim.x / nA;                 // 2N
+    Item it;
+    it.cb = s_item / sweeps;
+    const int s = s_item - it.cb * sweeps;
+    it.n = s >> 1;
+    it.dir = s & 1;
+    const UttLens len = utt_lens<COMPACT>(a.xn, a.yn, it.n, a.T, a.U);
+    if (!COMPACT || len.ok) {   // (compact: an utterance with bad lengths has no plane of its own to sweep)
+        const bool hl = it.cb > 0, hr = it.cb + 1 < (len.Un + WAVE - 1) / WAVE;
+#define RNNT_WD_SWEEP(B)                                                                    \
+    do {                                                                                    \
+        if (hl) { if (hr) sweep<B, COMPACT, true, true>(a, it, len, nA, sm, &wg_bad);       \
+                  else sweep<B, COMPACT, true, false>(a, it, len, nA, sm, &wg_bad); }       \
+        else { if (hr) sweep<B, COMPACT, false, true>(a, it, len, nA, sm, &wg_bad);         \
+               else sweep<B, COMPACT, false, false>(a, it, len, nA, sm, &wg_bad); }         \
+    } while (0)
+        if (it.dir) RNNT_WD_SWEEP(true); else RNNT_WD_SWEEP(false);
+#undef RNNT_WD_SWEEP
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 && wg_bad) atomicOr(&a.redo[2 * it.n + it.dir], wg_bad);
+}
+
+}  // namespace wd
+
+size_t wd_mail_bytes(int N, int T, int U) {
+    const int nA = (U + WAVE - 1) / WAVE;
+    size_t bytes = nA < 2 ? 0 : (size_t)2 * N * (nA - 1) * wd::ring_pitch(T, U) * sizeof(wd::u64);
+#ifdef RNNT_WD_STATS       // the stamp table of the diagnostics build, behind the rings
+    bytes += (size_t)2 * N * nA * wd::trace_slots(T, U) * 8 * sizeof(wd::u64);
+#endif
+    return bytes;
+}
+
+// Needs a.redo, a.queue = a.redo + 2N with the launch counter behind it (and a.mail of wd_mail_bytes when U > 64);
+// zeroes redo, the queue head and the rings itself.  Sweeps it flags in a.redo (a lost hand-over: never observed
+// outside the short-spin build) are for the caller to redo with the single-workgroup kernel.
+hipError_t launch_lattice_wd(hipStream_t stream, const LatticeArgs& a0, int N) {
+    if (N <= 0) return hipSuccess;
+    const int nA = (a0.U + WAVE - 1) / WAVE;
+    if (!a0.redo || !a0.queue || (nA > 1 && !a0.mail) || a0.offs32) return hipErrorNotSupported;
+#ifdef RNNT_WD_STATS
+    if (!a0.mail) return hipErrorNotSupported;
+#endif
+    if ((long long)2 * N * nA >= (1ll << 31)) return hipErrorNotSupported;
+    LatticeArgs a = a0;
+    a.epoch = next_launch_epoch();
+    const size_t ring_bytes = nA < 2 ? 0 : (size_t)2 * N * (nA - 1) * wd::ring_pitch(a.T, a.U) * sizeof(wd::u64);
+    hipError_t e = launch_ring_prepare(stream, a.redo, 2 * N + 1, a.mail, ring_bytes);
+    if (e != hipSuccess) return e;
+    const dim3 grid(2 * N * nA), block(3 * WAVE);
+    if (a.offs)
+        wd::k_lattice_wd<true><<<grid, block, 0, stream>>>(a, nA);
+    else
+        wd::k_lattice_wd<false><<<grid, block, 0, stream>>>(a, nA);
+    return hipGetLastError();
+}
+
+}  // namespace rnnt

@@ -27,133 +27,11 @@
 
 #include "common.h"
 #include "kernels.h"
+#include "lattice_step.h"
 
 namespace rnnt {
 
 namespace ws {
-
-constexpr int K = 8;             // diagonals per block
-constexpr int RING = 4 * K;      // mailbox ring entries per column-block boundary
-constexpr int MAXA = 8;          // compute waves per workgroup (=> 512 columns per pass)
-constexpr int PSLOTS = 3;        // LDS ring of pair blocks
-constexpr int VSLOTS = 2;        // LDS ring of value blocks
-constexpr int DLOAD = 2;         // I/O wave loads pairs this many blocks before it writes them to LDS
-constexpr int NBR = DLOAD + 1;   // its register ring
-constexpr int SHIFT = DLOAD;     // global block g = local time + idx + SHIFT, so the first load is at g >= 0
-constexpr int TRASH = WAVE + K;
-constexpr int RSRC_WORD3 = 0x00020000;
-constexpr int OOB = (int)0x80000000;
-
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-
-struct Smem {   // per column block
-    f32x2 pairs[PSLOTS][K][WAVE];
-    float vals[VSLOTS][K][WAVE];
-    float mail[RING];
-    float trash[TRASH];
-};
-
-__device__ __forceinline__ void block_barrier() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
-}
-
-// K diagonals of the compute wave.  cur = this block's pairs (registers).  Values go to LDS.
-template <bool BETA, bool MASKED, bool MAIL>
-__device__ __forceinline__ void compute_block(const f32x2 (&cur)[K], const float mvec, float& Y, float& X,
-                                              const int d0, const int ucol_chk, const int Tn,
-                                              float* vslot /* [K][WAVE] + lane */, float* mail_slot) {
-    float first[K];
-#pragma unroll
-    for (int k = 0; k < K; ++k) first[k] = readlane(mvec, k);
-#define RNNT_PIN() __builtin_amdgcn_sched_barrier(0)
-    // A lone wave issues one instruction per ~5.8 cycles whatever it is (tools/ubench/step_order.hip),
-    // so the step is ordered to need NO hazard nops: the LDS write and the next skip/Y add sit between
-    // the value and the DPP that reads it (2 wait states), v_max sits behind v_exp_f32 (1 wait state),
-    // and the v_mov that seeds the next DPP's lane 0 is issued well before it.
-    float fk = first[0];
-    asm volatile("" : "+v"(fk));   // materialise the DPP's lane-0 seed in a VGPR here, not next to the DPP
-    RNNT_PIN();
-    float pval = 0.0f;
-#pragma unroll
-    for (int k = 0; k < K; ++k) {
-        float skip, emit;
-        if constexpr (BETA) {
-            // beta: the value of the previous diagonal is published, then extended by this cell's
-            // blank log-prob -- both read `Y` and sit between its producer and the DPP below
-            if (k > 0) {
-#ifndef RNNT_WS_NOVAL
-                vslot[(k - 1) * WAVE] = pval;
-#endif
-                RNNT_PIN();
-            }
-            skip = Y + cur[k].x;
-            RNNT_PIN();
-        } else {
-            skip = Y;
-        }
-        const float left = wave_shr1(fk, X);                                           // chain
-        RNNT_PIN();
-        if constexpr (BETA) {
-            emit = left + cur[k].y;                                                    // chain (scalar add: the
-                                                                                       // file is built with -fno-slp-vectorize)
-        } else {
-            emit = left;
-        }
-        RNNT_PIN();
-        // lse(skip, emit) = max + log1p(exp(-|skip-emit|)), see lattice.hip
-        const float t = skip - emit;                                                   // chain
-        RNNT_PIN();
-        const float m = -__builtin_fabsf(t) * 1.44269504088896340736f;                 // chain
-        RNNT_PIN();
-        const float e = __builtin_amdgcn_exp2f(m);                                     // chain
-        RNNT_PIN();
-        const float mx = __builtin_fmaxf(skip, emit);                                  // fills the trans wait state
-        RNNT_PIN();
-        const float u = 1.0f + e;                                                      // chain
-        RNNT_PIN();
-        const float l2 = __builtin_amdgcn_logf(u);                                     // chain
-        RNNT_PIN();
-        if (k + 1 < K) { fk = first[k + 1]; asm volatile("" : "+v"(fk)); RNNT_PIN(); }
-        const float um1 = u - 1.0f;
-        RNNT_PIN();
-        const float c = e - um1;
-        RNNT_PIN();
-        const float l = __builtin_fmaf(l2, 0.693147180559945309417f, c);               // chain
-        RNNT_PIN();
-        const float val = mx + l;                                                      // chain
-        RNNT_PIN();
-        float Yn, Xn;
-        if constexpr (BETA) {
-            Yn = val; Xn = val;
-        } else {
-            Xn = val + cur[k].y;                                                       // chain (feeds the DPP)
-            RNNT_PIN();
-#ifndef RNNT_WS_NOVAL
-            vslot[k * WAVE] = val;
-#endif
-            RNNT_PIN();
-            Yn = val + cur[k].x;
-            RNNT_PIN();
-        }
-        if constexpr (MASKED) {
-            const bool live = (unsigned)(d0 + k - ucol_chk) < (unsigned)Tn;
-            Y = live ? Yn : Y;
-            X = live ? Xn : X;
-        } else {
-            Y = Yn; X = Xn;
-        }
-        pval = val;
-        if constexpr (MAIL) { mail_slot[k] = X; RNNT_PIN(); }
-    }
-    if constexpr (BETA) {
-#ifndef RNNT_WS_NOVAL
-        vslot[(K - 1) * WAVE] = pval;
-#endif
-    }
-#undef RNNT_PIN
-}
 
 template <bool BETA, bool COMPACT>
 __device__ __forceinline__ void sweep(const LatticeArgs& a, const int n, Smem* smem) {
@@ -275,6 +153,14 @@ __device__ __forceinline__ void sweep(const LatticeArgs& a, const int n, Smem* s
         ps0 += (NBR - ((ps0 % NBR) + NBR) % NBR) % NBR;
         const int ps1 = hi - DLOAD;                        // exclusive
         for (; p < p_end && p < ps0; ++p) io_any(p, std::true_type{});
+        // Empty the memory queue once, where the compiler can see it: the guarded steps above issue their loads and
+        // stores under conditions, so on the path into the loop the waitcnt pass can only assume the worst for the
+        // registers they filled, and it would make the first step of EVERY iteration wait for (nearly) everything in
+        // flight -- a memory round trip every third block (round 4: `vmcnt(3)` at the loop head in the ISA).  With a
+        // known-empty queue here only the loop's own back edge decides, and that one it counts exactly.
+#ifndef RNNT_WS_NO_DRAIN
+        __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0)
+#endif
         for (; p + NBR <= ps1; p += NBR) {
             io_step(p, std::integral_constant<int, 0>{}, std::false_type{});
             io_step(p + 1, std::integral_constant<int, 1>{}, std::false_type{});
