@@ -237,17 +237,20 @@ size_t rnnt_amd_debug_redo_offset(int N, int T, int U);
 
 /*
  * Which arithmetic sweeps the lattice of the workspace-based calls (rnnt_amd_loss, rnnt_amd_loss_compact):
- *   0 auto       probability domain (fp64 mantissa + per-column exponent) where it is the faster
- *                kernel -- long lattices: T >= 640, T >= 2U, U <= 512, padded layout, 2N*ceil(U/64) <= the number of compute units (256) --
- *                and the log domain elsewhere;
- *   1 logdomain  always the reference's arithmetic (fp32 log-sum-exp per cell, core_gather.cu:22-35,106-126);
- *   2 pd         probability domain wherever it is supported (padded layout, U <= 512), log domain elsewhere.
- * Both agree with each other and with the reference to fp32 rounding on short lattices; on long ones the log
- * domain accumulates ~ulp(|alpha|) per step (1e-2 on the gradients at T=1500, U=300) and the probability domain
- * does not (7e-4), so results depend on the route -- and, on `auto`, on the batch shape.  Pin it for bit-stable
- * results across batch shapes.  Process-wide, read once per call, may be changed at any time; the initial value
- * comes from the environment variable RNNT_LATTICE (logdomain | pd).  The reference-named entry points of Part 1
- * always run the log domain on the caller's layout.  Returns the previous setting, or -1 for an unknown value.
+ *   0 auto       (default) the reference's arithmetic: fp32 log-sum-exp per cell (core_gather.cu:22-35,106-126).
+ *                Results are the same bits whatever the batch they were computed in: the kernel is chosen by shape
+ *                (one workgroup per sweep / one per 64-column block), both run the same step function;
+ *   1 logdomain  the same, said explicitly (kept from the rounds in which `auto` took the probability domain on long
+ *                lattices of small batches);
+ *   2 pd         probability domain (fp64 mantissa + per-column exponent) wherever it is supported
+ *                (padded or native compact layout, U <= 512), log domain elsewhere.  Opt-in: closer to exact arithmetic
+ *                on long lattices -- the log domain accumulates ~ulp(|alpha|) per step (1e-2 on the gradients at T=1500,
+ *                U=300, the reference's included), the probability domain does not (7e-4) -- at the reference's speed
+ *                or better only while 2N*ceil(U/64) <= the number of compute units.
+ * Process-wide, read once per call, may be changed at any time (not thread-safe: concurrent callers that want different
+ * routes must serialise); the initial value comes from the environment variable RNNT_LATTICE (logdomain | pd).  The
+ * reference-named entry points of Part 1 always run the log domain.  Returns the previous setting, or -1 for an
+ * unknown value.
  */
 int rnnt_amd_set_lattice(int route);
 int rnnt_amd_get_lattice(void);

@@ -17,16 +17,17 @@ The bar (BASELINE.json: "within 1e-4 fp32"; VERDICT r1: no additive slack at the
 path is at most HIP_VS_ORACLE x as far from exact arithmetic as the reference-ordered fp32 oracle is; where
 fp32 itself is good to 1e-4 (c2) the absolute bar applies as well.
 
-Every configuration runs on BOTH lattice routes (warp_rnnt_amd.set_lattice, VERDICT r2 #1):
-  "logdomain"  the reference's arithmetic (fp32 log-sum-exp per cell).  Asserted against the ORACLE directly:
-               max |hip - oracle| and its 99.9th percentile within LOGDOMAIN_VS_ORACLE (2e-4 / 5e-5 at
-               T = 150, 3e-3 / 5e-5 at T = 1500) at every size -- two fp32 implementations of one operation order (they differ in the lse
-               transcendentals and in the association of the first column's prefix sums) -- plus the fp64 bar.
-  "auto"       what a caller gets by default: the probability-domain kernel at c4/c5, the log-domain kernel at
-               c2/c3.  Asserted: the fp64 bar, and max |hip - fp64| <= AUTO_VS_FP64_MAX absolute.
-`test_results_do_not_depend_on_the_batch_when_the_route_is_pinned` states the contract that goes with it: on
-"auto" the same utterance may get gradients that differ at the level of the log-domain kernel's own fp64 error
-when the batch shape moves it to the other kernel; with a pinned route they are bit-identical.
+Every configuration runs on BOTH lattice routes (warp_rnnt_amd.set_lattice):
+  "auto"       what a caller gets by default (round 4 on): the reference's arithmetic, fp32 log-sum-exp per cell, on
+               whichever log-domain kernel the shape selects (they produce the same bits, tests/test_gpu_wd.py).
+               Asserted against the ORACLE directly: max |hip - oracle| and its 99.9th percentile within
+               LOGDOMAIN_VS_ORACLE (2e-4 / 5e-5 at T = 150, 3e-3 / 5e-5 at T = 1500) at every size -- two fp32
+               implementations of one operation order (they differ in the lse transcendentals and in the association
+               of the first column's prefix sums) -- plus the fp64 bar.
+  "pd"         the opt-in probability-domain kernel (c4/c5; the log-domain kernel at c2/c3, which it does not
+               support / is not faster for).  Asserted: the fp64 bar, and max |hip - fp64| <= PD_VS_FP64_MAX absolute.
+`test_results_do_not_depend_on_the_batch` states the contract that goes with it: on every route an utterance gets the
+same bits whatever batch it is computed in, like the reference's (blockIdx.z = n, core.cu:49).
 
 With RNNT_PARITY_TABLE=<file.json> every case appends its numbers there (label RNNT_PARITY_BUILD);
 profiles/r02_parity_errors.json is the committed copy for the default, log-domain and libm builds.
@@ -50,8 +51,8 @@ HIP_VS_ORACLE = 1.5     # max |hip - fp64| <= HIP_VS_ORACLE * max |oracle - fp64
 # sit on the best path where |alpha| ~ 6e3 makes one ulp 5e-4); the full c5 batch (8 ragged utterances) 2.0e-3 /
 # 1.4e-5 -- for scale: both are 2.3e-2 / 8.8e-3 away from fp64 there
 LOGDOMAIN_VS_ORACLE = {"short": (2e-4, 5e-5), "long": (3e-3, 5e-5)}
-AUTO_VS_FP64_MAX = 2e-3            # route "auto": max |hip - fp64| (measured: 7.2e-4 at c4, 1.4e-3 at c5)
-ROUTES = ["auto", "logdomain"]
+PD_VS_FP64_MAX = 2e-3              # route "pd": max |hip - fp64| (measured: 7.2e-4 at c4, 1.4e-3 at c5)
+ROUTES = ["auto", "pd"]
 COST_RTOL_FP64 = 2e-6
 COST_RTOL_ORACLE = 1e-5
 
@@ -167,13 +168,14 @@ def three_way(name, costs, gpairs, lp2_f32, lp2_f64, xn, yn, lam, fp64_utts=None
     assert row["grad_hip_vs_fp64"]["max"] <= HIP_VS_ORACLE * row["grad_oracle_vs_fp64"]["max"], row
     assert row["grad_hip_vs_fp64"]["p999"] <= HIP_VS_ORACLE * row["grad_oracle_vs_fp64"]["p999"], row
     if abs_bar is not None:
-        assert row["grad_hip_vs_oracle"]["max"] <= abs_bar, row
-    if route == "logdomain":
+        # the reference's arithmetic: against the oracle; the probability domain (not that arithmetic): against fp64
+        assert row["grad_hip_vs_fp64" if route == "pd" else "grad_hip_vs_oracle"]["max"] <= abs_bar, row
+    if route != "pd":
         bar_max, bar_p999 = LOGDOMAIN_VS_ORACLE["long" if T >= 640 else "short"]
         assert row["grad_hip_vs_oracle"]["max"] <= bar_max, row
         assert row["grad_hip_vs_oracle"]["p999"] <= bar_p999, row
     else:
-        assert row["grad_hip_vs_fp64"]["max"] <= AUTO_VS_FP64_MAX, row
+        assert row["grad_hip_vs_fp64"]["max"] <= PD_VS_FP64_MAX, row
     # path-occupancy invariants (exact in exact arithmetic), to the accuracy just established
     # (gradient errors are relative errors of exp(.), so a row/column sum is off by about as much as its
     # largest entry)
@@ -254,34 +256,39 @@ def _pairs_grads(lp, ys, xn, yn, route):
     return c.cpu().numpy(), g.cpu().numpy()
 
 
-def test_results_do_not_depend_on_the_batch_when_the_route_is_pinned():
-    """The reference's per-utterance results never depend on N (blockIdx.z = n, core.cu:49).  Here the default
-    route picks the lattice kernel from the batch shape (N=16 at T=1500, U=300: probability domain; N=32: log
-    domain), so on "auto" one utterance's gradients may differ between the two batches -- by no more than the
-    log-domain arithmetic's own distance from exact arithmetic, asserted below -- and with the route pinned they
-    are bit-identical."""
+def test_results_do_not_depend_on_the_batch():
+    """The reference's per-utterance results never depend on N (blockIdx.z = n, core.cu:49).  Neither do these, on any
+    route: the default route picks its log-domain KERNEL from the batch shape (one workgroup per 64-column block at
+    N=16 and N=32, T=1500, U=300; one per sweep from 2N*ceil(U/64) > 2 x the compute units on), but the kernels share
+    the step function.  Bit-identical per utterance between a batch and its first half, and -- on the default route
+    -- between the two kernels (tests/test_gpu_wd.py does that at more shapes)."""
+    import warp_rnnt_amd
     from warp_rnnt_amd import ops
     xs, ys, xn, yn = device_case(6, 32, 1500, 300, 50)
     lp2_64 = pairs_fp64(xs[:2], ys[:2])
     lp = ops.log_softmax(xs, out=xs)
     half = slice(0, 16)
-    for route in ("logdomain", "pd"):
+    for route in ("auto", "logdomain", "pd"):
         c32, g32 = _pairs_grads(lp, ys, xn, yn, route)
         c16, g16 = _pairs_grads(lp[half].contiguous(), ys[half].contiguous(), xn[half], yn[half], route)
         np.testing.assert_array_equal(c32[half], c16, err_msg=route)
         np.testing.assert_array_equal(g32[half], g16, err_msg=route)
-    c32, g32 = _pairs_grads(lp, ys, xn, yn, "auto")
-    c16, g16 = _pairs_grads(lp[half].contiguous(), ys[half].contiguous(), xn[half], yn[half], "auto")
+        if route == "auto":
+            ca, ga = c32, g32
+        if route == "logdomain":
+            np.testing.assert_array_equal(c32, ca)         # `logdomain` and `auto` are the same arithmetic
+            np.testing.assert_array_equal(g32, ga)
+    for kernel in ("ws", "wd"):
+        old = warp_rnnt_amd.set_logdomain_kernel(kernel)
+        try:
+            ck, gk = _pairs_grads(lp, ys, xn, yn, "auto")
+        finally:
+            warp_rnnt_amd.set_logdomain_kernel(old)
+        np.testing.assert_array_equal(ck, ca, err_msg=kernel)
+        np.testing.assert_array_equal(gk, ga, err_msg=kernel)
     ones = np.ones((2, 299), dtype=np.int32)
     c64, g64 = transduce_np.transduce_batch(lp2_64, ones, xn[:2], yn[:2], blank=0, fast=True)
-    mask = live_mask(2, 1500, 300, xn[:2], yn[:2])
-    far = max(dist(g32[:2], g64, mask)["max"], dist(g16[:2], g64, mask)["max"])   # the worse kernel's fp64 error
-    delta = dist(g32[:2], g16[:2], mask)["max"]
-    print(json.dumps({"case": "same utterance, N=32 vs N=16 batch, route auto", "max_delta": delta,
-                      "max_fp64_distance_of_the_worse_kernel": far}))
-    assert delta <= 1.5 * far
-    np.testing.assert_allclose(c32[half], c16, rtol=COST_RTOL_ORACLE)
-    np.testing.assert_allclose(c16[:2], c64, rtol=COST_RTOL_FP64)
+    np.testing.assert_allclose(ca[:2], c64, rtol=COST_RTOL_FP64)
 
 
 def test_c5_full_per_rank_batch_forward():
@@ -330,11 +337,11 @@ def test_c5_full_per_rank_batch_forward():
         print(json.dumps(row))
         record(row)
         assert row["grad_hip_vs_fp64"]["max"] <= HIP_VS_ORACLE * row["grad_oracle_vs_fp64"]["max"], row
-        if route == "logdomain":
+        if route != "pd":
             assert row["grad_hip_vs_oracle"]["max"] <= LOGDOMAIN_VS_ORACLE["long"][0], row
             assert row["grad_hip_vs_oracle"]["p999"] <= LOGDOMAIN_VS_ORACLE["long"][1], row
         else:
-            assert row["grad_hip_vs_fp64"]["max"] <= AUTO_VS_FP64_MAX, row
+            assert row["grad_hip_vs_fp64"]["max"] <= PD_VS_FP64_MAX, row
         tol = 4 * max(row["grad_hip_vs_fp64"]["max"], 1e-6)     # (the accuracy just established on utterance 0)
         for n in range(N):
             tn, un = int(xn[n]), int(yn[n]) + 1

@@ -236,7 +236,7 @@ def test_reference_named_compact_entry_points():
 @pytest.mark.parametrize("N,Tm,Um,V,lam", [
     (3, 40, 12, 9, 0.0),          # one column block
     (3, 70, 150, 5, 0.02),        # three column blocks, ragged ends in different blocks
-    (2, 700, 200, 6, 0.0),        # long lattice: what "auto" hands to the probability-domain kernel
+    (2, 700, 200, 6, 0.0),        # long lattice: the distributed log-domain kernel on "auto", the probability domain on "pd"
     (5, 9, 1, 4, 0.0),            # no labels at all
 ])
 def test_compact_on_both_lattice_routes(route, N, Tm, Um, V, lam):

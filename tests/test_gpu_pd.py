@@ -1,8 +1,7 @@
-"""The probability-domain lattice kernel is chosen automatically only for long lattices of small batches
-(csrc/lattice.hip: launch_lattice); here it is forced on for everything it supports (warp_rnnt_amd.set_lattice("pd");
-a subprocess because the second test loads another build of the library) and compared with the fp32 oracle.  The default routing is what the
-other GPU tests exercise: short lattices run the log-domain kernels, c4 and c5 of
-tests/test_gpu_baseline_sizes.py the probability-domain one."""
+"""The probability-domain lattice kernel is opt-in (warp_rnnt_amd.set_lattice("pd"); csrc/lattice.hip: launch_lattice):
+here it runs everything it supports (a subprocess because the second test loads another build of the library) and is
+compared with the fp32 oracle.  The default route (the reference's log-domain arithmetic) is what the other GPU tests
+exercise; c4 and c5 of tests/test_gpu_baseline_sizes.py run on both."""
 import os
 import subprocess
 import sys

@@ -65,6 +65,23 @@ def test_same_bits_as_the_single_workgroup_kernel(N, T, U, ragged):
         np.testing.assert_allclose(g_wd.cpu().numpy(), o["grads"], atol=1e-4 if T + U <= 250 else 3e-4)
 
 
+def test_default_route_picks_either_kernel_by_batch_and_the_bits_do_not_change():
+    """csrc/lattice.hip: launch_lattice takes the distributed kernel while 2N*ceil(U/64) <= 2 x the compute units and the
+    single-workgroup one beyond.  One utterance, computed in a batch on either side of that line: the same bits."""
+    N, T, U = 200, 700, 130                # 2 * 200 * 3 = 1200 column blocks: one workgroup per sweep
+    logits, labels, xn, yn = make_case(31, 4, T, U, 5, ragged=True)
+    lp2_small = torch.tensor(_pairs(logits, labels), device=DEV)
+    lp2 = lp2_small.repeat(N // 4, 1, 1, 1).contiguous()
+    txn = torch.tensor(np.tile(xn, N // 4), device=DEV)
+    tyn = torch.tensor(np.tile(yn, N // 4), device=DEV)
+    c_big, g_big = ops.loss(lp2, None, txn, tyn, ops.IN_LOG_PROBS_GATHERED, ops.GRADS_GATHERED)
+    c_small, g_small = ops.loss(lp2_small, None, txn[:4].contiguous(), tyn[:4].contiguous(), ops.IN_LOG_PROBS_GATHERED,
+                                ops.GRADS_GATHERED)                         # 24 column blocks: one workgroup each
+    torch.cuda.synchronize()
+    assert torch.equal(c_big[:4], c_small) and torch.equal(g_big[:4], g_small)
+    assert torch.equal(c_big[-4:], c_small) and torch.equal(g_big[-4:], g_small)
+
+
 def test_wider_than_one_workgroup_can_sweep():
     """U > 512: the single-workgroup kernel cannot take it (lattice.hip's striped kernel does); the distributed one
     simply has more column blocks.  Against the oracle."""

@@ -20,10 +20,11 @@ LATTICE_ROUTES = ("auto", "logdomain", "pd")
 
 def set_lattice(route):
     """Select the arithmetic of the alpha/beta sweeps for every later call in this process (include/warp_rnnt_amd.h,
-    ``rnnt_amd_set_lattice``): ``"auto"`` (default; the probability-domain kernel on long lattices, the log-domain
-    kernel elsewhere -- fastest, results depend on the batch shape at the 1e-2 level of fp32 log-domain drift on
-    long lattices), ``"logdomain"`` (always the reference's fp32 log-sum-exp arithmetic) or ``"pd"`` (the
-    probability-domain kernel wherever it is supported).  Returns the previous route."""
+    ``rnnt_amd_set_lattice``): ``"auto"`` (default) and ``"logdomain"`` are the reference's fp32 log-sum-exp per cell
+    -- the same bits whatever the batch an utterance is computed in; ``"pd"`` is the probability-domain kernel wherever
+    it is supported (padded or compact layout, U <= 512): closer to exact arithmetic on long lattices (7e-4 instead of
+    1e-2 on the gradients at T=1500, U=300), not the reference's numbers.  Process-wide and not thread-safe: callers on
+    several threads that want different routes must serialise.  Returns the previous route."""
     if route not in LATTICE_ROUTES:
         raise ValueError(f"unknown lattice route {route!r}: expected one of {LATTICE_ROUTES}")
     return LATTICE_ROUTES[load().rnnt_amd_set_lattice(LATTICE_ROUTES.index(route))]
@@ -35,7 +36,8 @@ def get_lattice():
 
 @contextlib.contextmanager
 def lattice_route(route):
-    """``with warp_rnnt_amd.lattice_route("logdomain"): ...`` -- the route inside the block, the old one after it."""
+    """``with warp_rnnt_amd.lattice_route("pd"): ...`` -- the route inside the block, the old one after it (process-wide:
+    every thread's calls see it while the block runs)."""
     old = set_lattice(route)
     try:
         yield

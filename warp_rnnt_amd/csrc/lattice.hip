@@ -54,6 +54,7 @@ constexpr int RING = 4 * K;   // mailbox ring entries per wave boundary
 #define RNNT_MAXW 16
 #endif
 constexpr int MAXW = RNNT_MAXW;   // waves per workgroup
+namespace ws { constexpr int MAXA_HOST = 8; }   // column blocks one lattice_ws.hip workgroup sweeps (its MAXA)
 constexpr int MAIL_TRASH = WAVE + K;   // per-wave dump area for the lanes that are not lane 63
 
 struct Cell { float b, l; };  // blank / label log-prob of one lattice cell
@@ -466,13 +467,14 @@ int set_lattice_route(int route) {
     return route_setting().exchange(route, std::memory_order_relaxed);
 }
 
-// compute units of the current device (one query per process and device; 256 on MI355X): the probability-domain kernel
-// wants a CU per column block -- one more workgroup than CUs and the last ones start when the first finish
-// (N=25 at U=300: 121 us, N=26: 164 us, log domain 160; profiles/r03_lattice_probe_threshold.txt)
-static int device_cus() {
+// compute units of the stream's device (one query per process and device; 256 on MI355X): the kernels with one
+// workgroup per column block want CUs of their own for them
+static int device_cus(hipStream_t stream) {
     static std::atomic<int> cached[64];
     int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    // the device that owns the stream the kernels go to (not necessarily the current one)
+    if (hipStreamGetDevice(stream, &dev) != hipSuccess && hipGetDevice(&dev) != hipSuccess) return 256;
+    if (dev < 0 || dev >= 64) return 256;
     int n = cached[dev].load(std::memory_order_relaxed);
     if (n == 0) {
         if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
@@ -537,26 +539,24 @@ hipError_t launch_lattice(hipStream_t stream, const LatticeArgs& a, int N, int l
         // ... and behind them the single-workgroup log-domain kernel for the sweeps they flagged (normally none:
         // its workgroups read one flag and return)
         auto redo_behind = [&]() {
+#ifdef RNNT_PROBE_NO_REDO_LAUNCH   // timing probe only: what the (normally idle) kernel behind costs
+            return hipSuccess;
+#endif
             const hipError_t e = launch_lattice_ws(stream, a, N);
             return e != hipErrorNotSupported ? e : launch_single(stream, a, N, loader);
         };
 #ifndef RNNT_LATTICE_LOGDOMAIN
-        // Long lattices of small batches: probability-domain sweep, one workgroup per 64-column block
-        // (lattice_pd.hip).  Where it pays, measured on MI355X (tools/lattice_probe.py, us per alpha+beta sweep,
-        // probability domain / single-workgroup log domain):
-        //   N=16: T=1500 U=64 65/93, U=300 114/158, U=512 141/211; T=3000 U=500 (N=8) 200/376; T=700 U=100 53/60;
-        //         but T=400 U=100 40/40, T=150 U=40 20/16 (the hand-over lag between the column blocks and the extra
-        //         launches are only recovered on long sweeps);
-        //   T=1500 U=300: N=32 166/161, N=64 254/201 (its column blocks want a CU each).
-        // U <= 512 because the log-domain kernel behind it must be able to redo a sweep.
+        // Probability-domain sweep, one workgroup per 64-column block (lattice_pd.hip): only when the caller asks for
+        // it (route "pd": closer to exact arithmetic on long lattices), wherever it is supported
+        // (U <= 512 because the log-domain kernel behind it must be able to redo a sweep).  Until round 4 it was
+        // also what `auto` took for long lattices of small batches, because it was the fastest kernel there (N=16,
+        // T=1500, U=300: 117 us against 157 for lattice_ws.hip); lattice_wd.hip closes that gap with the reference's
+        // arithmetic (121 us), so the default no longer trades the reference's numerics -- and results that do not
+        // depend on the batch shape -- for 4 us.
         // The route is a per-call setting (LatticeArgs::route <- rnnt_amd_set_lattice(); the environment variable
-        // RNNT_LATTICE=logdomain|pd only provides its initial value): ROUTE_LOGDOMAIN pins the reference's
-        // arithmetic, ROUTE_PD takes the probability-domain kernel wherever it is supported.
+        // RNNT_LATTICE=logdomain|pd only provides its initial value).
         const bool pd_ok = ring_ok && pd_shape_supported(a.T, a.U);
-        bool use_pd = pd_ok && (long long)2 * N * nA <= device_cus() && a.T >= 640 && a.T >= 2 * a.U;
-        if (a.route == ROUTE_LOGDOMAIN) use_pd = false;
-        if (a.route == ROUTE_PD) use_pd = pd_ok;
-        if (use_pd) {
+        if (a.route == ROUTE_PD && pd_ok) {
             const hipError_t e = launch_lattice_pd(stream, a, N);
             if (e == hipSuccess) return redo_behind();
             if (e != hipErrorNotSupported) return e;
@@ -564,8 +564,16 @@ hipError_t launch_lattice(hipStream_t stream, const LatticeArgs& a, int N, int l
 #endif
         // Log domain.  Two kernels, the same bits: lattice_ws.hip (all column blocks of a sweep in one workgroup; one
         // pass covers U <= 512) and lattice_wd.hip (one workgroup per column block, boundary columns through L2).
+        // Which one, measured on MI355X (tools/lattice_routes.py, profiles/r04_lattice_routes.txt; us per alpha+beta
+        // launch, ws / wd): N=16, T=1500: U=64 93/88, U=128 113/103, U=300 156/122, U=512 210/145; T=3000 U=500
+        // (N=8) 372/222; U=300 by batch: N=32 159/128, N=48 175/156, N=64 204/220, N=128 306/424; T=1000 U=200:
+        // N=64 97/94, N=128 130/184; T=500 U=100: N=64 47/49; T=400 U=100 (N=16) 40/42, T=150 U=40 16/20.
+        // The distributed kernel wins while its column blocks find CUs of their own (its loader's LDS-DMA pieces
+        // queue up behind each other when five workgroups share a CU) and the sweep is long enough to recover two
+        // extra launches (ring preparation in front, the idle redo kernel behind).
         const int kern = logdomain_kernel();
-        bool use_wd = ring_ok && nA >= 2;
+        bool use_wd = ring_ok && (long long)2 * N * nA <= 2ll * device_cus(stream) && a.T >= 640 && (nA >= 2 || a.T >= 1024);
+        if (nA > ws::MAXA_HOST) use_wd = ring_ok;             // wider than one workgroup sweeps: column blocks or stripes
         if (kern == 1) use_wd = false;
         if (kern == 2) use_wd = ring_ok;
         if (use_wd) {
