@@ -12,7 +12,9 @@ all-reduce.
 
 Timing: [--preload-ms of streaming copies, see its help] -> W untimed warm-up steps -> barrier + synchronize ->
 exactly K timed steps -> barrier + synchronize; ms_per_step = that wall time / K, MAX over ranks.  The preload is not
-the benchmark step and is reported in the JSON line (`preload_ms`; 0 = measure from a cold start).
+the benchmark step and is reported in the JSON line (`preload_ms`).  The same W/K protocol is run once more IN FRONT
+of that, from an idle GPU and without the preload, and reported next to it as `ms_per_step_cold`, and twice behind it
+with the lattice route pinned (`ms_per_step_logdomain`, `ms_per_step_pd`); `lattice_route` names what the headline ran.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--config c2|c3|c4|c5] [--preload-ms P]
 """
@@ -141,6 +143,27 @@ def cpu_baseline(cfg, utts):
                       f"(log_softmax + gather + loss + grads), {dt:.2f} s wall, OpenMP over rows/utterances"}
 
 
+def parity_of_timed_batch(lp, ys, xn, yn, lam, utts=2):
+    """Gradients of the first `utts` utterances of the timed batch on the route the headline ran, against the fp32
+    oracle (the reference's operation order) on the same log-probs: max and 99.9th percentile of |hip - oracle| over the
+    (blank, label) gradient pairs.  Outside the timed region; per-utterance results do not depend on the batch."""
+    import numpy as np
+    import oracle
+    from warp_rnnt_amd import ops
+    k = min(utts, lp.shape[0])
+    sub = lp[:k].contiguous()
+    c, g = ops.loss(sub, ys[:k].contiguous(), xn[:k].contiguous(), yn[:k].contiguous(), ops.IN_LOG_PROBS_DENSE,
+                    ops.GRADS_GATHERED, 0, lam)
+    torch.cuda.synchronize()
+    lp2 = oracle.gather_f32(sub.cpu().numpy(), ys[:k].cpu().numpy(), 0)
+    ref = oracle.rnnt_loss_f32(lp2, None, xn[:k].cpu().numpy(), yn[:k].cpu().numpy(), blank=-1, fastemit_lambda=lam,
+                               scan_mode=1)
+    d = np.abs(g.cpu().numpy().astype(np.float64) - ref["grads"].astype(np.float64)).ravel()
+    return {"max_abs_grad_vs_oracle": float(d.max()), "max_abs_grad_vs_oracle_p999": float(np.quantile(d, 0.999)),
+            "max_rel_cost_vs_oracle": float(np.abs(c.cpu().numpy() / ref["costs"] - 1).max()),
+            "parity_sample": f"{k} utterances of the timed batch, gathered gradient pairs, fp32 oracle (oracle/rnnt_oracle.c)"}
+
+
 def gather_roofline(lp, ys, N, T, U, V, reps):
     """The gather kernel of the loss entry alone (k_to_diagonal<true>: dense log-probs -> diagonal-major pairs),
     HIP events on the launch stream.  Two prices: the ALGORITHMIC bytes of SURVEY.md 8(d) (16 B per cell: 8 read, 8
@@ -172,6 +195,10 @@ def gather_roofline(lp, ys, N, T, U, V, reps):
            "achieved": round(alg / (ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
            "frac": round(alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "algorithmic_bytes": alg,
            "kernel_ms": round(ms, 4), "traffic": None}
+    # SURVEY.md 8(d)'s DRAM-granularity floor of the access pattern: min(4V, 128) + 8 bytes per cell
+    floor = (min(4.0 * V, 128.0) + 8.0) * cells
+    out["survey_floor_bytes"] = floor
+    out["survey_floor_frac"] = round(floor / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
     if cells <= 8_000_000:
         # distinct 128-byte lines that hold a blank or a label log-prob of some cell (exact, on the host)
         lab = np.zeros((N, U), dtype=np.int64)
@@ -216,19 +243,38 @@ def dry_run(a, world, rank):
     os.environ.setdefault("MASTER_PORT", "29511")
     dist.init_process_group(a.backend if a.backend == "gloo" else "gloo", rank=rank, world_size=world)
     N = CONFIGS[a.config][0]
+    n_local = N
+    if a.global_batch:
+        from warp_rnnt_amd.distributed import shard_bounds
+        lo, hi = shard_bounds(a.global_batch, rank, world)
+        if hi - lo < 1:
+            sys.exit("--global-batch must give every rank at least one utterance")
+        n_local = hi - lo
     total = torch.tensor([float(rank + 1)])
+    t0 = time.perf_counter()
     for _ in range(a.warmup + a.steps):
         total = torch.tensor([float(rank + 1)])
         dist.all_reduce(total)
     dist.barrier()
+    dt = time.perf_counter() - t0
+    # the same collectives the measured path uses for its bookkeeping: MAX / spread of the per-rank time, utterances
+    ts = [torch.zeros((1,), dtype=torch.float64) for _ in range(world)]
+    dist.all_gather(ts, torch.tensor([dt], dtype=torch.float64))
+    owned = torch.tensor([float(n_local)])
+    dist.all_reduce(owned)
     ranks = dist.get_world_size()
     if rank == 0:
+        n_global = a.global_batch if a.global_batch else N * world
         emit(json.dumps({"metric": "dry run (launcher / process group / reduction only, nothing measured)",
                           "value": None, "unit": "utterances/s", "n_gpus": world, "steps": a.steps,
-                          "warmup": a.warmup, "ms_per_step": None, "higher_is_better": True, "scaling": "weak",
+                          "warmup": a.warmup, "ms_per_step": None, "higher_is_better": True,
+                          "scaling": "strong" if a.global_batch else "weak",
                           "dry": True, "backend": "gloo", "rccl_ranks": ranks,
                           "reduced_scalar": float(total.item()),
-                          "config": {"workload": f"{a.config}: N={N}/rank (global {N * world})"}}))
+                          "utterances_owned_by_all_ranks": int(owned.item()),
+                          "ms_per_step_rank_min_max": [round(min(float(x) for x in ts) * 1e3, 3),
+                                                       round(max(float(x) for x in ts) * 1e3, 3)],
+                          "config": {"workload": f"{a.config}: N={n_local}/rank on rank 0 (global {n_global})"}}))
     dist.destroy_process_group()
 
 
@@ -340,7 +386,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    if a.preload_ms > 0:
+    def preload(ms):
         # Sustained-load conditioning, disclosed in the JSON line.  A GPU that goes from idle to a streaming load slows
         # both kernels by 10-15 % from ~4 to ~14 ms after the onset, then settles (tools/step_series.py: steps 3-12 of a
         # cold process; with 30 ms of back-to-back streaming kernels in front, step 0 already runs at the settled
@@ -352,26 +398,69 @@ def main():
         src = xs.view(-1)[:n_el] if xs.numel() >= n_el else torch.zeros((n_el,), device=dev)
         scratch = torch.empty_like(src)
         per_copy_ms = 2.0 * n_el * 4 / 5.0e12 * 1e3                  # ~0.21 ms at ~5 TB/s
-        for _ in range(int(a.preload_ms / per_copy_ms) + 1):
+        for _ in range(int(ms / per_copy_ms) + 1):
             torch.mul(src, 1.0, out=scratch)
         del scratch, src
-    for _ in range(a.warmup):
-        step(last=True)          # the closing reduction is warmed up too
-    fence()
-    t0 = time.perf_counter()
-    for i in range(a.steps):
-        total = step(i, last=(i == a.steps - 1))
-    fence()
-    dt = time.perf_counter() - t0
+
+    def timed_run(preload_ms, events):
+        """[preload] -> W warm-up steps -> fence -> K timed steps -> fence.  Returns (seconds of this rank, last total)."""
+        if preload_ms > 0:
+            preload(preload_ms)
+        for _ in range(a.warmup):
+            step(last=True)          # the closing reduction is warmed up too
+        fence()
+        t0 = time.perf_counter()
+        total = None
+        for i in range(a.steps):
+            total = step(i if events else None, last=(i == a.steps - 1))
+        fence()
+        return time.perf_counter() - t0, total
+
+    def over_ranks(dt_local):
+        """MAX over ranks (the contract), plus the spread."""
+        if dist is None:
+            return dt_local, dt_local, dt_local
+        t = torch.tensor([dt_local], dtype=torch.float64, device=dev)
+        ts = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(ts, t)
+        vals = [float(x.item()) for x in ts]
+        return max(vals), min(vals), max(vals)
+
+    # 1. the same protocol from an idle GPU, no preload (what rounds 1-2 and a first step after a pause measure)
+    torch.cuda.synchronize()
+    time.sleep(0.05)
+    dt_cold, _ = timed_run(0.0, events=False)
+    dt_cold = over_ranks(dt_cold)[0]
+    # 2. the headline: sustained-load state
+    dt, total = timed_run(a.preload_ms, events=True)
+    import warp_rnnt_amd
+    route_ran = f"{warp_rnnt_amd.get_lattice()} -> {warp_rnnt_amd.last_lattice_kernel()}"
+    dt, dt_min, dt_max = over_ranks(dt)
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = t.item()
         one = torch.ones((1,), device=dev)
         dist.all_reduce(one)                      # ranks that really took part in an RCCL all-reduce
         rccl_ranks = int(one.item())
     ms_step = dt * 1e3 / a.steps
     loss_val = float(total.item())
+    # 3. the same with the lattice route pinned: the reference's arithmetic (the default), the probability domain (opt-in)
+    pinned = {}
+    for route in ("logdomain", "pd"):
+        with warp_rnnt_amd.lattice_route(route):
+            d, _ = timed_run(a.preload_ms, events=False)
+            pinned[route] = (over_ranks(d)[0] * 1e3 / a.steps, warp_rnnt_amd.last_lattice_kernel())
+    # the only exchange of the multi-GPU path, alone: K asynchronous scalar all-reduces behind each other
+    allreduce_us = None
+    if dist is not None:
+        x = torch.ones((1,), device=dev)
+        for _ in range(3):
+            dist.all_reduce(x)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        hs = [dist.all_reduce(x, async_op=True) for _ in range(a.steps)]
+        for h in hs:
+            h.wait()
+        torch.cuda.synchronize()
+        allreduce_us = (time.perf_counter() - t1) / a.steps * 1e6
 
     # dominant kernel (dense log-softmax stream): average launch duration from the HIP events
     # recorded inside the timed region, on the stream the kernel runs on
@@ -415,6 +504,18 @@ def main():
         torch.cuda.synchronize()
         extras["loss_only_ms"] = round(e0.elapsed_time(e1) / reps, 4)
         extras["fused_from_logits_ms"] = round(e1.elapsed_time(e2) / reps, 4)
+        # the UNCHANGED caller's forward step (benchmark.py:65-70 verbatim: F.log_softmax, then the loss)
+        for _ in range(2):
+            warp_rnnt.rnnt_loss(torch.nn.functional.log_softmax(xs, -1), ys, xn, yn, gather=gather, fastemit_lambda=lam)
+        torch.cuda.synchronize()
+        e3, e4 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e3.record()
+        for _ in range(reps):
+            warp_rnnt.rnnt_loss(torch.nn.functional.log_softmax(xs, -1), ys, xn, yn, gather=gather, fastemit_lambda=lam)
+        e4.record()
+        torch.cuda.synchronize()
+        extras["step_torch_log_softmax_ms"] = round(e3.elapsed_time(e4) / reps, 4)
+        extras.update(parity_of_timed_batch(lp, ys, xn, yn, lam))
         if gather:
             extras["roofline_gather"] = gather_roofline(lp, ys, N, T, U, V, reps)
         del lp
@@ -464,6 +565,13 @@ def main():
             "steps": a.steps,
             "warmup": a.warmup,
             "ms_per_step": round(ms_step, 4),
+            "ms_per_step_cold": round(dt_cold * 1e3 / a.steps, 4),     # same W/K from an idle GPU, no preload
+            "lattice_route": route_ran,                               # setting -> kernel the headline's steps launched
+            "ms_per_step_logdomain": round(pinned["logdomain"][0], 4),
+            "ms_per_step_pd": round(pinned["pd"][0], 4),
+            "lattice_kernels_pinned": {k: v[1] for k, v in pinned.items()},
+            "ms_per_step_rank_min_max": [round(dt_min * 1e3 / a.steps, 4), round(dt_max * 1e3 / a.steps, 4)],
+            "allreduce_scalar_us": None if allreduce_us is None else round(allreduce_us, 1),
             "higher_is_better": True,
             "scaling": "strong" if a.global_batch else "weak",
             "vs_baseline": round(value / pub, 2) if pub else None,

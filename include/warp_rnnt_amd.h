@@ -267,6 +267,11 @@ int rnnt_amd_get_lattice(void);
 int rnnt_amd_set_logdomain_kernel(int kernel);
 int rnnt_amd_get_logdomain_kernel(void);
 
+/* Diagnostics (bench.py's `lattice_route`, tests): the lattice kernel the calling thread's last loss call launched --
+ * 1 lattice_ws (log domain, one workgroup per sweep), 2 lattice_wd (log domain, one per column block), 3 lattice_pd
+ * (probability domain), 4 the single-role kernel of lattice.hip (reference layouts, stripes); 0 before the first call. */
+int rnnt_amd_debug_last_lattice_kernel(void);
+
 /* Library version, for the host-side loader. */
 int rnnt_amd_version(void);
 

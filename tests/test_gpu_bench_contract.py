@@ -43,6 +43,15 @@ def test_c2_line_has_the_contract_fields_and_is_self_consistent():
         assert k in c, k
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == d["unit"]
     assert d["value"] > c["value"]          # (a sanity bound, not a claim: the GPU path is faster than the CPU port)
+    # the parity contract travels with the number: what ran, the same protocol on each pinned route and
+    # from a cold start, and the gradients of the timed batch against the reference-order oracle
+    assert d["lattice_route"].startswith("auto -> lattice_")
+    for k in ("ms_per_step_cold", "ms_per_step_logdomain", "ms_per_step_pd"):
+        assert 0.5 * d["ms_per_step"] < d[k] < 3.0 * d["ms_per_step"], (k, d[k], d["ms_per_step"])
+    assert d["lattice_kernels_pinned"]["pd"] == "lattice_pd" and d["lattice_kernels_pinned"]["logdomain"].startswith("lattice_w")
+    assert 0.0 <= d["max_abs_grad_vs_oracle_p999"] <= d["max_abs_grad_vs_oracle"] <= 2e-4      # T = 150: BASELINE's 1e-4 class
+    assert d["max_rel_cost_vs_oracle"] <= 1e-5
+    assert d["step_torch_log_softmax_ms"] > 0
 
 
 def test_c4_line_prices_the_loss_entry_and_the_gather_too():
@@ -55,5 +64,11 @@ def test_c4_line_prices_the_loss_entry_and_the_gather_too():
     assert lp["bound"] == "hbm" and 0.0 < lp["frac"] < 1.0 and lp["kernels_ms"] < d["ms_per_step"]
     g = d["roofline_gather"]
     assert 0.0 < g["frac"] < g["line_frac"] < 1.0 and g["kernel_ms"] < lp["kernels_ms"]
+    assert g["frac"] < g["survey_floor_frac"] < 1.0               # min(4V,128)+8 = 136 B per cell
+    # the headline runs the reference's arithmetic on the distributed kernel; its distance from the oracle at this size
+    # is one rounding of |alpha| ~ 6e3 on a handful of best-path cells (tests/test_gpu_baseline_sizes.py: 3e-3 / 5e-5)
+    assert d["lattice_route"] == "auto -> lattice_wd"
+    assert d["max_abs_grad_vs_oracle"] <= 3e-3 and d["max_abs_grad_vs_oracle_p999"] <= 5e-5
+    assert d["step_torch_log_softmax_ms"] > d["ms_per_step"]       # torch's log-softmax is the slower one
     # the two halves of the step, as the events saw them, make up the step (launch gaps and event packets aside)
     assert abs(d["roofline"]["kernel_ms"] + lp["kernels_ms"] - d["ms_per_step"]) < 0.15 * d["ms_per_step"]

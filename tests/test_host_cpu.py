@@ -290,6 +290,29 @@ def test_bench_self_launches_ranks_gloo_dry():
     assert bad.returncode != 0 and b"launcher started 1 rank" in bad.stdout
 
 
+def test_bench_eight_ranks_weak_and_strong_gloo_dry():
+    """What the driver's SCALE run does on an 8-GPU node, rehearsed on CPU: `bench.py --gpus 8` starts eight ranks,
+    every rank joins the group, the scalar reduction sees all eight, the per-rank time spread is gathered; and with
+    --global-batch 128 (BASELINE.json configs[3] as a strong-scaling run) the shards add up to the global batch."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    for extra, scaling, owned in (([], "weak", 8 * 16), (["--global-batch", "128"], "strong", 128),
+                                  (["--global-batch", "100"], "strong", 100)):
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--backend", "gloo", "--dry",
+                              "--steps", "2", "--warmup", "1"] + extra, env=env, stdout=subprocess.PIPE,
+                             stderr=subprocess.STDOUT, timeout=600)
+        text = out.stdout.decode()
+        assert out.returncode == 0, text
+        lines = [ln for ln in text.splitlines() if ln.startswith("{")]
+        assert len(lines) == 1, text
+        rec = json.loads(lines[0])
+        assert rec["n_gpus"] == 8 and rec["rccl_ranks"] == 8 and rec["dry"] is True and rec["scaling"] == scaling
+        assert rec["reduced_scalar"] == 36.0                      # 1 + ... + 8
+        assert rec["utterances_owned_by_all_ranks"] == owned
+        lo, hi = rec["ms_per_step_rank_min_max"]
+        assert 0 < lo <= hi
+
+
 def test_compiled_binding_is_built_and_checks_arguments_like_the_reference():
     """warp_rnnt._C_native (csrc/binding.cpp): the reference's check order and texts (binding.cpp:32-51, test.py:15-32)
     come from TORCH_CHECK there; whatever can be observed without a GPU is observed here."""

@@ -56,4 +56,12 @@ def set_logdomain_kernel(kernel):
     return LOGDOMAIN_KERNELS[load().rnnt_amd_set_logdomain_kernel(LOGDOMAIN_KERNELS.index(kernel))]
 
 
+LATTICE_KERNELS = ("none", "lattice_ws", "lattice_wd", "lattice_pd", "lattice (single role)")
+
+
+def last_lattice_kernel():
+    """Name of the lattice kernel this thread's last loss call launched (``rnnt_amd_debug_last_lattice_kernel``)."""
+    return LATTICE_KERNELS[load().rnnt_amd_debug_last_lattice_kernel()]
+
+
 __version__ = "0.1.0"

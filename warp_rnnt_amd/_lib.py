@@ -50,6 +50,7 @@ SYMBOLS = {
     "rnnt_amd_get_lattice": (_i, []),
     "rnnt_amd_set_logdomain_kernel": (_i, [_i]),
     "rnnt_amd_get_logdomain_kernel": (_i, []),
+    "rnnt_amd_debug_last_lattice_kernel": (_i, []),
     "rnnt_amd_version": (_i, []),
 }
 

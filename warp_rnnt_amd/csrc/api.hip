@@ -63,6 +63,8 @@ int rnnt_amd_set_logdomain_kernel(int kernel) { return set_logdomain_kernel(kern
 
 int rnnt_amd_get_logdomain_kernel(void) { return logdomain_kernel(); }
 
+int rnnt_amd_debug_last_lattice_kernel(void) { return last_lattice_kernel(); }
+
 size_t rnnt_amd_workspace_size(int N, int T, int U) {
     if (!dims_ok(N, T, U)) return 0;
     return carve(nullptr, N, T, U, nullptr);

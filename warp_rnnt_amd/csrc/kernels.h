@@ -90,6 +90,7 @@ unsigned next_launch_epoch();     // host part of the launch epoch: random start
 // Which kernel serves the log-domain route where both can (same bits either way): 0 = by shape, 1 = single workgroup
 // per sweep (lattice_ws.hip), 2 = one workgroup per column block (lattice_wd.hip).  Initial value from the
 // environment variable RNNT_LOGDOMAIN_KERNEL=ws|wd.
+int last_lattice_kernel();        // what the calling thread's last launch_lattice ran: 1 ws, 2 wd, 3 pd, 4 single-role (0 none yet)
 int logdomain_kernel();
 int set_logdomain_kernel(int k);  // returns the previous setting, or -1 for an unknown value
 hipError_t launch_grads(hipStream_t stream, const GradArgs& a, int N, int loader, int writer);

@@ -519,6 +519,9 @@ hipError_t launch_single(hipStream_t stream, const LatticeArgs& a, int N, int lo
 }
 }  // namespace
 
+static thread_local int g_last_kernel = 0;
+int last_lattice_kernel() { return g_last_kernel; }
+
 int logdomain_kernel() { return logdomain_kernel_setting().load(std::memory_order_relaxed); }
 
 int set_logdomain_kernel(int k) {
@@ -558,6 +561,7 @@ hipError_t launch_lattice(hipStream_t stream, const LatticeArgs& a, int N, int l
         const bool pd_ok = ring_ok && pd_shape_supported(a.T, a.U);
         if (a.route == ROUTE_PD && pd_ok) {
             const hipError_t e = launch_lattice_pd(stream, a, N);
+            g_last_kernel = 3;
             if (e == hipSuccess) return redo_behind();
             if (e != hipErrorNotSupported) return e;
         }
@@ -578,13 +582,16 @@ hipError_t launch_lattice(hipStream_t stream, const LatticeArgs& a, int N, int l
         if (kern == 2) use_wd = ring_ok;
         if (use_wd) {
             const hipError_t e = launch_lattice_wd(stream, a, N);
+            g_last_kernel = 2;
             if (e == hipSuccess) return redo_behind();
             if (e != hipErrorNotSupported) return e;
         }
         const hipError_t e = launch_lattice_ws(stream, plain, N);
+        g_last_kernel = 1;
         if (e != hipErrorNotSupported) return e;
     }
 #endif
+    g_last_kernel = 4;
     return launch_single(stream, plain, N, loader);
 }
 
