@@ -220,7 +220,8 @@ rnntStatus_t rnnt_amd_gather(rnntStream_t stream, const float *log_probs, const 
                              float *gathered, int N, int T, int U, int V, int blank);
 
 /* Diagnostics (used by tools/lattice_probe.py): re-run only the alpha/beta sweep on the
- * (blank,label) pairs a previous rnnt_amd_loss call left in `workspace`. */
+ * (blank,label) pairs a previous rnnt_amd_loss call left in `workspace` -- they survive a call with
+ * RNNT_GRADS_GATHERED_DIAGONAL only (every other kind produces its gradients in their place). */
 rnntStatus_t rnnt_amd_debug_lattice_only(rnntStream_t stream, void *workspace, const int *xn,
                                          const int *yn, int N, int T, int U);
 

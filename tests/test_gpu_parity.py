@@ -161,6 +161,51 @@ def test_seeded_vs_oracle_all_entry_points(N, T, U, V, ragged, lam, blank):
     np.testing.assert_allclose(gb, g2, atol=GRAD_ATOL)
 
 
+def test_staged_forms_of_the_entry_points_from_a_million_cells_on():
+    """From 2^20 lattice cells on (csrc/api.hip: STAGED_FROM_CELLS) the reference-named C entry points stage the pairs
+    in the caller's `grads`, sweep on the tuned kernels, park the gradient pairs in alphas / betas and turn the layout
+    through LDS tiles (gathered) or expand whole dense rows (dense, which then no longer depends on the caller's
+    zero-fill); the native gathered-gradient form takes the tiled turn as well.  All of them against the fp32 oracle,
+    with ragged lengths, FastEmit and blank != 0; the dense entry also on a `grads` buffer full of junk."""
+    N, T, U, V, lam, blank = 6, 420, 430, 5, 0.01, 1
+    assert N * T * U >= 1 << 20
+    logits, labels, xn, yn = make_case(99, N, T, U, V, ragged=True, blank=blank)
+    yn[1] = 0                                                   # an utterance without labels
+    lp = np_log_softmax32(logits)
+    ref = oracle.rnnt_loss_f32(lp, labels, xn, yn, blank=blank, fastemit_lambda=lam, scan_mode=1)
+    lp2 = oracle.gather_f32(lp, labels, blank)
+    ref2 = oracle.rnnt_loss_f32(lp2, labels, xn, yn, blank=-1, fastemit_lambda=lam, scan_mode=1)
+    atol = 5e-4                     # (T + U = 850: one rounding of |alpha| ~ 2e3 on best-path cells)
+    ca, ga = _call_ref_abi(lp, labels, xn, yn, blank, lam)
+    np.testing.assert_allclose(ca, ref["costs"], rtol=COST_RTOL)
+    np.testing.assert_allclose(ga, ref["grads"], atol=atol)
+    assert not ga[ref["grads"] == 0].any()                     # nothing but the two slots of live cells
+    cb, gb = _call_ref_abi(lp2, labels, xn, yn, -1, lam)
+    np.testing.assert_allclose(cb, ref2["costs"], rtol=COST_RTOL)
+    np.testing.assert_allclose(gb, ref2["grads"], atol=atol)
+    np.testing.assert_array_equal(ca, cb)
+    c2, g2 = run_native(lp2, labels, xn, yn, blank=-1, lam=lam)
+    np.testing.assert_array_equal(c2, cb)
+    np.testing.assert_array_equal(g2, gb)                       # the same kernels behind both
+    c, g = run_native(lp, labels, xn, yn, blank=blank, lam=lam)
+    np.testing.assert_array_equal(g, ga)
+    # dense entry on a dirty `grads`: every row is written whole
+    import warp_rnnt_amd
+    L = warp_rnnt_amd.load()
+    d = dev()
+    xs, ys, txn, tyn = t32(lp), t32(labels), t32(xn), t32(yn)
+    grads = torch.full(xs.shape, 7.0, dtype=torch.float32, device=d)
+    counts = torch.zeros((N, 2 * U), dtype=torch.int32, device=d)
+    alphas, betas = torch.empty((N, T, U), device=d), torch.empty((N, T, U), device=d)
+    costs = torch.empty((N,), device=d)
+    st = L.run_warp_rnnt(torch.cuda.current_stream().cuda_stream, counts.data_ptr(), alphas.data_ptr(), betas.data_ptr(),
+                         ys.data_ptr(), xs.data_ptr(), grads.data_ptr(), costs.data_ptr(), txn.data_ptr(), tyn.data_ptr(),
+                         N, T, U, V, blank, lam)
+    torch.cuda.synchronize()
+    assert st == 0
+    np.testing.assert_array_equal(grads.cpu().numpy(), ga)
+
+
 def test_calls_stress():
     """test.py:190-212: N=128,T=100,U=90,V=3, random yn, two seeds -- the reference only checks
     that nothing hangs; here the values are checked too."""

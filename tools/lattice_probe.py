@@ -87,7 +87,7 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
     ws = torch.empty((L.rnnt_amd_workspace_size(N, T, U),), dtype=torch.uint8, device=dev)
     st = L.rnnt_amd_loss(stream, ws.data_ptr(), 1, lp2.data_ptr(), None, xn.data_ptr(), yn.data_ptr(),
-                         costs.data_ptr(), grads.data_ptr(), 0, N, T, U, 2, 0, 0.0)
+                         costs.data_ptr(), grads.data_ptr(), 1, N, T, U, 2, 0, 0.0)
     assert st == 0
     torch.cuda.synchronize()
     csum = float(costs.double().sum().item())

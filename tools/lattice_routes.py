@@ -50,7 +50,7 @@ def run(shape, L, dev):
         warp_rnnt_amd.set_logdomain_kernel(kern)
         # the pairs are consumed in place when gradients are produced: rebuild them for every route
         st = L.rnnt_amd_loss(stream, ws.data_ptr(), 1, lp2.data_ptr(), None, xn.data_ptr(), yn.data_ptr(),
-                             costs.data_ptr(), grads.data_ptr(), 0, N, T, U, 2, 0, 0.0)
+                             costs.data_ptr(), grads.data_ptr(), 1, N, T, U, 2, 0, 0.0)
         assert st == 0, st
         torch.cuda.synchronize()
         planes[name] = (ws[:cells * 4].view(torch.float32).clone(), ws[plane:plane + cells * 4].view(torch.float32).clone(),

@@ -49,7 +49,7 @@ assert trace_off + nwords * 8 <= ws.numel()
 for rep in range(3):
     ws[trace_off:trace_off + nwords * 8] = 0
     st = L.rnnt_amd_loss(s, ws.data_ptr(), 1, lp2.data_ptr(), None, xn.data_ptr(), yn.data_ptr(), costs.data_ptr(),
-                         grads.data_ptr(), 0, N, T, U, 2, 0, 0.0)
+                         grads.data_ptr(), 1, N, T, U, 2, 0, 0.0)
     assert st == 0
     torch.cuda.synchronize()
 tr = ws[trace_off:trace_off + nwords * 8].view(torch.int64).cpu().numpy().reshape(2 * N, nA, slots, 8)

@@ -12,6 +12,10 @@ using namespace rnnt;
 namespace {
 
 constexpr size_t ALIGN = 256;
+// Lattices from this many cells on take the multi-pass forms (stage, sweep on the tuned kernels, turn the layout
+// through LDS tiles); smaller ones are launch-bound and keep the single-kernel forms (tools/cabi_probe.py: N=16, T=150,
+// U=40: 24 us in two launches against 35 in five; N=16, T=1500, U=300: 500 against 274)
+constexpr size_t STAGED_FROM_CELLS = (size_t)1 << 20;
 inline size_t align_up(size_t x) { return (x + ALIGN - 1) / ALIGN * ALIGN; }
 
 struct Workspace {
@@ -84,6 +88,14 @@ size_t rnnt_amd_debug_redo_offset(int N, int T, int U) {
     return reinterpret_cast<uintptr_t>(w.redo) - ALIGN;
 }
 
+// The reference-named entry points (core.h:29-39) own no workspace: everything they need has to come out of the buffers
+// the caller's binding allocates (binding.cpp:58-75) -- and does: the tuned kernels want the (blank,label) pairs in the
+// diagonal-major layout, which is exactly one (N,T,U,2) plane, and `grads` is at least that large and not yet written.
+// So the pairs are staged in `grads`, the sweeps run on them (alphas / betas are the caller's scratch already, in the
+// diagonal-major layout since round 1), and the gradient kernel -- which reads the log-probs from the caller's input
+// again -- overwrites the staging area with the result.  Until round 4 these entries ran the single-role kernel with
+// per-lane row-major / dense loads: 0.50 / 2.67 ms at N=16, T=1500, U=300 (V=50), now 0.27 / 0.64
+// (tools/cabi_probe.py, profiles/r04_cabi_probe.txt).
 rnntStatus_t run_warp_rnnt(rnntStream_t stream, unsigned int* counts, float* alphas, float* betas,
                            const int* labels, const float* log_probs, float* grads, float* costs,
                            const int* xn, const int* yn, int N, int T, int U, int V, int blank,
@@ -91,8 +103,48 @@ rnntStatus_t run_warp_rnnt(rnntStream_t stream, unsigned int* counts, float* alp
     if (!dims_ok(N, T, U) || V < 1 || blank < 0 || blank >= V) return RNNT_STATUS_INVALID_ARGUMENT;
     if (N == 0) return RNNT_STATUS_SUCCESS;
     float* ll = reinterpret_cast<float*>(counts);   // (N,2U) uint32 scratch: first N words reused
-    LatticeArgs la{log_probs, labels, xn, yn, alphas, betas, ll, T, U, V, blank};
-    if (launch_lattice(stream, la, N, LOAD_DENSE) != hipSuccess) return RNNT_STATUS_WARP_FAILED;
+    const size_t cells = (size_t)N * T * U;
+    const bool stage = V >= 2 && (U == 1 || labels) && (int64_t)U * V < ((int64_t)1 << 31) && cells >= STAGED_FROM_CELLS;
+    if (stage) {
+        // dense (N,T,U,V) grads, zeroed by the caller: its head is the staging area -- pairs, then (room permitting:
+        // V >= 4 or so) the flags and hand-over rings of the distributed lattice kernel -- and is zeroed again before the
+        // gradient kernel writes its two slots per cell
+        char* base = reinterpret_cast<char*>(grads);
+        const size_t avail = cells * (size_t)V * sizeof(float);
+        size_t off = align_up(cells * 2 * sizeof(float));
+        int* redo = nullptr;
+        unsigned long long* mail = nullptr;
+        const size_t flag_bytes = align_up(((size_t)N * 2 + 2) * sizeof(int)), ring_bytes = lattice_mail_bytes(N, T, U);
+        if (reinterpret_cast<uintptr_t>(base) % ALIGN == 0 && off + flag_bytes + align_up(ring_bytes) <= avail) {
+            redo = reinterpret_cast<int*>(base + off);
+            off += flag_bytes;
+            mail = reinterpret_cast<unsigned long long*>(base + off);
+            off += align_up(ring_bytes);
+        }
+        if (launch_gather(stream, log_probs, labels, grads, N, T, U, V, blank, true) != hipSuccess)
+            return RNNT_STATUS_WARP_FAILED;
+        LatticeArgs la{grads, nullptr, xn, yn, alphas, betas, ll, T, U, 2, 0, nullptr, redo, redo ? redo + 2 * N : nullptr, mail};
+        la.route = ROUTE_LOGDOMAIN;
+        if (launch_lattice(stream, la, N, LOAD_SKEWED) != hipSuccess) return RNNT_STATUS_WARP_FAILED;
+        // gradient pairs in place of the log-prob pairs (coalesced both ways), parked in the caller's alphas / betas --
+        // dead by then -- and expanded from there into whole dense rows, zeros included: the staging area is
+        // overwritten with the rest, and nothing depends on the caller's zero-fill any more (the slot writes of the
+        // direct form below cost 0.8 ms at N=16, T=1500, U=300, V=50, this 0.37)
+        const bool split_ok = reinterpret_cast<uintptr_t>(grads) % 16 == 0 && reinterpret_cast<uintptr_t>(alphas) % 8 == 0 &&
+                              reinterpret_cast<uintptr_t>(betas) % 8 == 0;
+        if (split_ok) {
+            GradArgs gs{grads, nullptr, xn, yn, alphas, betas, ll, grads, costs, nullptr, T, U, 2, 0, fastemit_lambda};
+            if (launch_grads(stream, gs, N, LOAD_SKEWED, WRITE_SKEWED2) != hipSuccess) return RNNT_STATUS_GRADS_BLANK_FAILED;
+            if (launch_split_pairs(stream, grads, alphas, betas, cells) != hipSuccess) return RNNT_STATUS_GRADS_LABEL_FAILED;
+            if (launch_expand_split(stream, alphas, betas, labels, xn, yn, grads, N, T, U, V, blank) != hipSuccess)
+                return RNNT_STATUS_GRADS_LABEL_FAILED;
+            return RNNT_STATUS_SUCCESS;
+        }
+        if (hipMemsetAsync(grads, 0, off < avail ? off : avail, stream) != hipSuccess) return RNNT_STATUS_WARP_FAILED;
+    } else {
+        LatticeArgs la{log_probs, labels, xn, yn, alphas, betas, ll, T, U, V, blank};
+        if (launch_lattice(stream, la, N, LOAD_DENSE) != hipSuccess) return RNNT_STATUS_WARP_FAILED;
+    }
     GradArgs ga{log_probs, labels, xn, yn, alphas, betas, ll, grads, costs, nullptr,
                 T, U, V, blank, fastemit_lambda};
     if (launch_grads(stream, ga, N, LOAD_DENSE, WRITE_DENSE_SLOTS) != hipSuccess)
@@ -107,6 +159,25 @@ rnntStatus_t run_warp_rnnt_gather(rnntStream_t stream, unsigned int* counts, flo
     if (!dims_ok(N, T, U)) return RNNT_STATUS_INVALID_ARGUMENT;
     if (N == 0) return RNNT_STATUS_SUCCESS;
     float* ll = reinterpret_cast<float*>(counts);
+    const size_t cells = (size_t)N * T * U;
+    const bool staged = cells >= STAGED_FROM_CELLS && reinterpret_cast<uintptr_t>(grads) % 16 == 0 &&
+                        reinterpret_cast<uintptr_t>(alphas) % 8 == 0 && reinterpret_cast<uintptr_t>(betas) % 8 == 0;
+    if (staged) {
+        // (N,T,U,2) grads = one pair plane: staging area first, result afterwards.  No room for hand-over rings here:
+        // the sweeps run on the single-workgroup log-domain kernel.
+        if (launch_reskew(stream, log_probs, grads, N, T, U) != hipSuccess) return RNNT_STATUS_WARP_FAILED;
+        LatticeArgs la{grads, nullptr, xn, yn, alphas, betas, ll, T, U, 2, 0};
+        la.route = ROUTE_LOGDOMAIN;
+        if (launch_lattice(stream, la, N, LOAD_SKEWED) != hipSuccess) return RNNT_STATUS_WARP_FAILED;
+        // gradient pairs in place of the log-prob pairs, parked in alphas / betas (dead by then), turned back into the
+        // row-major layout through LDS tiles: three coalesced passes (33 + 35 + 30 us at N=16, T=1500, U=300) instead
+        // of one whose row-major reads and writes are scattered over the diagonal-major thread order (158 us)
+        GradArgs gs{grads, nullptr, xn, yn, alphas, betas, ll, grads, costs, nullptr, T, U, 2, 0, fastemit_lambda};
+        if (launch_grads(stream, gs, N, LOAD_SKEWED, WRITE_SKEWED2) != hipSuccess) return RNNT_STATUS_GRADS_BLANK_FAILED;
+        if (launch_split_pairs(stream, grads, alphas, betas, cells) != hipSuccess) return RNNT_STATUS_GRADS_LABEL_FAILED;
+        if (launch_unskew(stream, alphas, betas, grads, N, T, U) != hipSuccess) return RNNT_STATUS_GRADS_LABEL_FAILED;
+        return RNNT_STATUS_SUCCESS;
+    }
     LatticeArgs la{log_probs, nullptr, xn, yn, alphas, betas, ll, T, U, 2, 0};
     if (launch_lattice(stream, la, N, LOAD_ROWMAJOR2) != hipSuccess) return RNNT_STATUS_WARP_FAILED;
     GradArgs ga{log_probs, nullptr, xn, yn, alphas, betas, ll, grads, costs, nullptr,
@@ -159,9 +230,12 @@ rnntStatus_t rnnt_amd_loss(rnntStream_t stream, void* workspace, int input_kind,
     // 3. gradients + costs (+ guard).  For a dense result the pairs are produced in place in the
     //    workspace and expanded to full rows (zeros included) in one coalesced pass.
     float* gout = grads;
-    int writer = WRITE_ROWMAJOR2;
-    if (grads_kind == RNNT_GRADS_GATHERED_DIAGONAL) writer = WRITE_SKEWED2;
-    if (grads_kind == RNNT_GRADS_DENSE || grads_kind == RNNT_GRADS_NONE) { gout = w.ws2; writer = WRITE_SKEWED2; }
+    int writer = WRITE_SKEWED2;
+    // (row-major pairs for the caller: produced in place in the workspace like the others, then turned through LDS
+    //  tiles -- 33 + 30 us at N=16, T=1500, U=300 against 92 for row-major writes from the diagonal-major thread order)
+    const bool unskew_gathered = grads_kind == RNNT_GRADS_GATHERED && (size_t)N * T * U >= STAGED_FROM_CELLS;
+    if (grads_kind == RNNT_GRADS_GATHERED && !unskew_gathered) writer = WRITE_ROWMAJOR2;   // (launch-bound sizes: direct)
+    else if (grads_kind != RNNT_GRADS_GATHERED_DIAGONAL) gout = w.ws2;
     GradArgs ga{w.ws2, nullptr, xn, yn, w.alphas, w.betas, w.ll, gout, costs, w.mismatch,
                 T, U, 2, 0, fastemit_lambda};
     if (launch_grads(stream, ga, N, LOAD_SKEWED, writer) != hipSuccess)
@@ -169,6 +243,9 @@ rnntStatus_t rnnt_amd_loss(rnntStream_t stream, void* workspace, int input_kind,
     if (grads_kind == RNNT_GRADS_DENSE) {
         if (launch_expand(stream, w.ws2, labels, xn, yn, nullptr, grads, N, T, U, V, blank, 1) != hipSuccess)
             return RNNT_STATUS_EXPAND_FAILED;
+    }
+    if (unskew_gathered) {
+        if (launch_unskew(stream, w.ws2, nullptr, grads, N, T, U) != hipSuccess) return RNNT_STATUS_EXPAND_FAILED;
     }
     return RNNT_STATUS_SUCCESS;
 }

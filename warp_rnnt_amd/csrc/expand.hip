@@ -81,6 +81,30 @@ struct PaddedRows {    // (N,T,U,V) output, diagonal-major pairs (gather backwar
         return expand_cell(row, g2, labels, xn, yn, scale, T, U, V, blank, overwrite);
     }
 };
+struct SplitRows {     // as PaddedRows, the two channels in two float planes (the reference-named dense C entry, api.hip)
+    const float* ga; const float* gb; const int* labels; const int* xn; const int* yn;
+    int T, U, V, blank;
+    __device__ __forceinline__ ExpandCell operator()(unsigned cell) const {
+        const unsigned frame = cell / (unsigned)U;
+        const int u = (int)(cell - frame * (unsigned)U);
+        const unsigned n = frame / (unsigned)T;
+        const int t = (int)(frame - n * (unsigned)T);
+        int r = t + u;
+        r = r >= T ? r % T : r;
+        const size_t at = ((size_t)n * T + r) * (size_t)U + u;
+        ExpandCell c;
+        c.gB = ga[at];
+        c.gL = gb[at];
+        c.lab = (u < U - 1) ? labels[(size_t)n * (U - 1) + u] : blank;
+        if ((unsigned)c.lab >= (unsigned)V) c.lab = -1;
+        // dense-kernel rule (core.cu:382-393), as PaddedRows in overwrite mode
+        const bool labvalid = (t < xn[n]) && (u < yn[n]);
+        if (!labvalid) c.lab = -1;
+        else if (c.lab == blank) c.gB = c.gL;
+        if (labvalid && c.lab == blank) c.lab = -1;
+        return c;
+    }
+};
 struct CompactRows {   // (STU,V) output, row-major pairs + loc (core_compact.cu:456-484)
     const float2* g2; const int64_t* loc; const int* cum_lens; const float* grad_cost;
     int N, V, blank;
@@ -177,6 +201,14 @@ hipError_t launch_expand(hipStream_t stream, const float* g2_skewed, const int* 
     if (cells64 == 0 || V == 0) return hipSuccess;
     const PaddedRows rows{reinterpret_cast<const float2*>(g2_skewed), labels, xn, yn, scale, T, U, V, blank,
                           overwrite_mode};
+    return launch_rows(stream, rows, dense, (unsigned)cells64, V, blank);
+}
+
+hipError_t launch_expand_split(hipStream_t stream, const float* ga_skewed, const float* gb_skewed, const int* labels,
+                               const int* xn, const int* yn, float* dense, int N, int T, int U, int V, int blank) {
+    const size_t cells64 = (size_t)N * T * U;
+    if (cells64 == 0 || V == 0) return hipSuccess;
+    const SplitRows rows{ga_skewed, gb_skewed, labels, xn, yn, T, U, V, blank};
     return launch_rows(stream, rows, dense, (unsigned)cells64, V, blank);
 }
 

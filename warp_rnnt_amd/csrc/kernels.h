@@ -102,6 +102,11 @@ hipError_t launch_log_softmax_backward(hipStream_t stream, const float* dy, cons
 hipError_t launch_gather(hipStream_t stream, const float* log_probs, const int* labels, float* out2,
                          int N, int T, int U, int V, int blank, bool skewed);
 hipError_t launch_reskew(hipStream_t stream, const float* lp2_rowmajor, float* ws2, int N, int T, int U);
+// diagonal-major pairs (b == nullptr: float2 plane at a; else two float planes) -> row-major (N,T,U,2)
+hipError_t launch_unskew(hipStream_t stream, const float* a, const float* b, float* out2_rowmajor, int N, int T, int U);
+hipError_t launch_split_pairs(hipStream_t stream, const float* pairs, float* a, float* b, size_t cells);
+hipError_t launch_expand_split(hipStream_t stream, const float* ga_skewed, const float* gb_skewed, const int* labels,
+                               const int* xn, const int* yn, float* dense, int N, int T, int U, int V, int blank);
 // compact (ragged packed) layout, core_compact.cu:403-436,456-484
 // reference-layout compact helpers (core.h:41-60 shims): row-major packed pairs + loc; costs from betas alone
 hipError_t launch_gather_compact_rowmajor(hipStream_t stream, const float* xs, const int* ys, const unsigned* xn,

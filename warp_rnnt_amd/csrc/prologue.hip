@@ -929,6 +929,87 @@ hipError_t launch_reskew(hipStream_t stream, const float* lp2_rowmajor, float* w
     return launch_to_diagonal(stream, lp2_rowmajor, nullptr, ws2, N, T, U, 2, 0, false);
 }
 
+// The way back: diagonal-major pairs -> row-major (N,T,U,2), the same 32x32 tiles walked the other way round (read by
+// diagonals: consecutive lanes = consecutive pairs of a diagonal-major row; written by frames).  SPLIT: the two
+// channels come from two float planes (the reference-named C entry points park the gradient pairs in the caller's
+// alphas / betas buffers while the (N,T,U,2) output is still their staging area, api.hip).
+template <bool SPLIT>
+__global__ void __launch_bounds__(256)
+k_from_diagonal(const float* __restrict__ a, const float* __restrict__ b, float2* __restrict__ out2, int T, int U,
+                int tiles_t, int tiles_u) {
+    __shared__ float2 tile[TT][TD + 1];
+    unsigned blk = blockIdx.x;
+    const int tu = blk % tiles_u; blk /= tiles_u;
+    const int tt = blk % tiles_t;
+    const int n = blk / tiles_t;
+    const int t0 = tt * TT, u0 = tu * TD;
+    const int ul = threadIdx.x & (TD - 1), tl0 = threadIdx.x >> 5;
+    const int u = u0 + ul;
+    const size_t nbase = (size_t)n * T * U;
+#pragma unroll
+    for (int k = 0; k < (TT + TD + 7) / 8; ++k) {
+        const int d = tl0 + 8 * k;
+        const int tl = d - ul;
+        if (d < TT + TD - 1 && tl >= 0 && tl < TT) {
+            const int t = t0 + tl;
+            if (t < T && u < U) {
+                int r = t + u;
+                r = r >= T ? r % T : r;
+                const size_t at = nbase + (size_t)r * U + u;
+                tile[tl][ul] = SPLIT ? make_float2(a[at], b[at]) : reinterpret_cast<const float2*>(a)[at];
+            }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < TT / 8; ++k) {
+        const int tl = tl0 + 8 * k, t = t0 + tl;
+        if (t < T && u < U) out2[nbase + (size_t)t * U + u] = tile[tl][ul];
+    }
+}
+
+hipError_t launch_unskew(hipStream_t stream, const float* a, const float* b, float* out2_rowmajor, int N, int T, int U) {
+    if ((size_t)N * T * U == 0) return hipSuccess;
+    const int tiles_t = (T + TT - 1) / TT, tiles_u = (U + TD - 1) / TD;
+    const size_t nblk = (size_t)N * tiles_t * tiles_u;
+    if (nblk >= ((size_t)1 << 31)) return hipErrorInvalidValue;
+    if (b)
+        k_from_diagonal<true><<<(unsigned)nblk, 256, 0, stream>>>(a, b, reinterpret_cast<float2*>(out2_rowmajor), T, U,
+                                                                  tiles_t, tiles_u);
+    else
+        k_from_diagonal<false><<<(unsigned)nblk, 256, 0, stream>>>(a, nullptr, reinterpret_cast<float2*>(out2_rowmajor),
+                                                                   T, U, tiles_t, tiles_u);
+    return hipGetLastError();
+}
+
+// (blank, label) pairs -> two planes, same cell order (a plain stream: 8 bytes in, 2 x 4 out per cell)
+__global__ void __launch_bounds__(256)
+k_split_pairs(const float4* __restrict__ src, float2* __restrict__ a, float2* __restrict__ b, size_t n2, const float2* tail,
+              float* ta, float* tb) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n2) {
+        const float4 v = src[i];                  // two cells
+        a[i] = make_float2(v.x, v.z);
+        b[i] = make_float2(v.y, v.w);
+    } else if (i == n2 && tail) {                 // an odd last cell
+        const float2 v = *tail;
+        *ta = v.x; *tb = v.y;
+    }
+}
+
+hipError_t launch_split_pairs(hipStream_t stream, const float* pairs, float* a, float* b, size_t cells) {
+    if (cells == 0) return hipSuccess;
+    const size_t n2 = cells / 2;
+    const bool odd = cells & 1;
+    const bool al = (reinterpret_cast<uintptr_t>(pairs) % 16 == 0) && (reinterpret_cast<uintptr_t>(a) % 8 == 0) &&
+                    (reinterpret_cast<uintptr_t>(b) % 8 == 0);
+    if (!al) return hipErrorInvalidValue;
+    k_split_pairs<<<(unsigned)((n2 + 1 + 255) / 256), 256, 0, stream>>>(
+        reinterpret_cast<const float4*>(pairs), reinterpret_cast<float2*>(a), reinterpret_cast<float2*>(b), n2,
+        odd ? reinterpret_cast<const float2*>(pairs) + (cells - 1) : nullptr, a + (cells - 1), b + (cells - 1));
+    return hipGetLastError();
+}
+
 
 // ---------------------------------------------------------------------------
 // Compact (ragged packed) layout, reference: core_compact.cu:403-436 (gather) and
