@@ -189,6 +189,18 @@ rnntStatus_t rnnt_amd_loss_compact(rnntStream_t stream, void *workspace, const f
                                    int N, int64_t STU, int Tmax, int Umax, int V, int blank,
                                    float fastemit_lambda);
 
+/* The same in ONE call with launch bounds the caller supplies (Tmax >= every xn, Umax >= every yn + 1; n_labels = the
+ * number of elements of ys): offsets, maxima and the shape checks stay on the device, nothing is read back, so the call
+ * can be captured into a HIP graph and costs no host synchronisation (rnnt_amd_compact_offsets + a read-back +
+ * rnnt_amd_loss_compact cost one).  A batch with a length outside the bounds (or < 1 frame), or whose sums are not
+ * STU / n_labels, is refused as a whole: costs = NaN, gradients zero, nothing outside the tensors is touched.
+ * Workspace: rnnt_amd_workspace_size_compact_bounded(N, STU, Tmax, Umax) bytes, 256-byte aligned. */
+size_t rnnt_amd_workspace_size_compact_bounded(int N, int64_t STU, int Tmax, int Umax);
+rnntStatus_t rnnt_amd_loss_compact_bounded(rnntStream_t stream, void *workspace, const float *xs, const int *ys,
+                                           int64_t n_labels, const int *xn, const int *yn, float *costs,
+                                           float *grads2, int64_t *loc, int N, int64_t STU, int Tmax, int Umax,
+                                           int V, int blank, float fastemit_lambda);
+
 /* Replaces run_scatter_grad_for_compact (core.h:56-60): (STU,V) d/d log_probs, fully written.
  * cum_lens (N,) int32 inclusive prefix sums of xn*(yn+1) (warp_rnnt/__init__.py:38). */
 rnntStatus_t rnnt_amd_compact_scatter_grads(rnntStream_t stream, const float *grad_costs,

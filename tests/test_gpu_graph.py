@@ -97,7 +97,8 @@ def test_training_step_replays():
         assert torch.equal(x.grad, want[k][1]), f"replay {rep}: d/d logits differ from eager"
 
 
-def test_replays_do_not_depend_on_what_the_workspace_holds():
+@pytest.mark.parametrize("route", ["pd", "auto"])
+def test_replays_do_not_depend_on_what_the_workspace_holds(route):
     """The workspace is caller scratch with unspecified contents (include/warp_rnnt_amd.h).  Under capture it is a
     tensor freed back to the graph's pool, so between replays anything may land in it: the previous replay's
     hand-over granules (the realistic case), constant bytes, random bytes.  k_prepare clears the rings and takes the
@@ -121,7 +122,8 @@ def test_replays_do_not_depend_on_what_the_workspace_holds():
                              costs.data_ptr(), grads.data_ptr(), ops.GRADS_GATHERED, N, T, U, V, 0, 0.0)
         assert st == 0
 
-    with warp_rnnt_amd.lattice_route("pd"):
+    # ("auto": the distributed log-domain kernel at this shape -- the same kind of rings, tags and launch counter)
+    with warp_rnnt_amd.lattice_route(route):
         eager = []
         for s in sets:
             for dst, src in zip(static, s):
@@ -150,3 +152,82 @@ def test_replays_do_not_depend_on_what_the_workspace_holds():
         torch.cuda.synchronize()
         assert torch.equal(costs, eager[k][0]), f"replay {rep}: costs {costs.tolist()} vs eager {eager[k][0].tolist()}"
         assert torch.equal(grads, eager[k][1]), f"replay {rep}: gradients differ from eager"
+
+
+def test_compact_with_launch_bounds_is_captured_and_replays():
+    """rnnt_loss(compact=True, max_frames=, max_labels=): the caller supplies the launch bounds, nothing is read back
+    from the device (rnnt_amd_loss_compact_bounded), so forward + backward capture into one graph.  Replayed with other
+    data and with the utterances in another order (same totals, other offsets and lengths); a batch that does not fit
+    the bounds comes back as NaN costs and zero gradients -- on replay too."""
+    import torch
+    import warp_rnnt
+    dev = torch.device("cuda:0")
+    V, Tb, Ub = 9, 700, 130                      # bounds: frames, labels (3 column blocks: the distributed kernel)
+    shapes = [(700, 130), (420, 64), (650, 100)]
+
+    def batch(order, seed):
+        g = torch.Generator(device="cpu").manual_seed(seed)
+        rows, labs, xn, yn = [], [], [], []
+        for i in order:
+            t, u = shapes[i]
+            rows.append(torch.log_softmax(torch.randn(t * (u + 1), V, generator=g) * 2.0, -1))
+            labs.append(torch.randint(1, V, (u,), generator=g, dtype=torch.int32))
+            xn.append(t); yn.append(u)
+        return (torch.cat(rows).to(dev), torch.cat(labs).to(dev), torch.tensor(xn, dtype=torch.int32, device=dev),
+                torch.tensor(yn, dtype=torch.int32, device=dev))
+
+    sets = [batch((0, 1, 2), 1), batch((2, 0, 1), 2), batch((1, 2, 0), 3)]
+    w = torch.tensor([0.5, 1.0, 1.5], device=dev)
+
+    def run(xs, ys, xn, yn, **kw):
+        x = xs.detach().requires_grad_(True)
+        costs = warp_rnnt.rnnt_loss(x, ys, xn, yn, compact=True, fastemit_lambda=0.01, **kw)
+        (costs * w).sum().backward()
+        return costs.detach(), x.grad
+
+    eager = []
+    for s_ in sets:
+        c_sync, g_sync = run(*s_)                                          # the path with its one host read-back
+        c_b, g_b = run(*s_, max_frames=Tb, max_labels=Ub)                  # bounds: none
+        torch.cuda.synchronize()
+        assert torch.equal(c_sync, c_b) and torch.equal(g_sync, g_b)
+        eager.append((c_b.clone(), g_b.clone()))
+
+    static = [t.clone() for t in sets[0]]
+    x_static = static[0].requires_grad_(True)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(2):
+            x_static.grad = None
+            c = warp_rnnt.rnnt_loss(x_static, static[1], static[2], static[3], compact=True, fastemit_lambda=0.01,
+                                    max_frames=Tb, max_labels=Ub)
+            (c * w).sum().backward()
+    torch.cuda.current_stream().wait_stream(side)
+    x_static.grad = None
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        costs = warp_rnnt.rnnt_loss(x_static, static[1], static[2], static[3], compact=True, fastemit_lambda=0.01,
+                                    max_frames=Tb, max_labels=Ub)
+        (costs * w).sum().backward()
+    for rep in range(9):
+        k = rep % len(sets)
+        with torch.no_grad():
+            for dst, src in zip(static, sets[k]):
+                dst.copy_(src)
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(costs, eager[k][0]), f"replay {rep}"
+        assert torch.equal(x_static.grad, eager[k][1]), f"replay {rep}: gradients differ from eager"
+    # a length beyond the bound: the replayed graph refuses the batch on the device
+    with torch.no_grad():
+        static[2].copy_(torch.tensor([701, 420, 649], dtype=torch.int32))
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.isnan(costs).all() and not x_static.grad.any()
+    # eager, same story, and totals that do not match the tensors
+    xs, ys, xn, yn = sets[0]
+    c, g = run(xs, ys, xn, yn, max_frames=600, max_labels=Ub)
+    assert torch.isnan(c).all() and not g.any()
+    c, g = run(xs, ys[:-1].contiguous(), xn, yn, max_frames=Tb, max_labels=Ub)
+    assert torch.isnan(c).all() and not g.any()

@@ -107,9 +107,16 @@ def rnnt_loss_gather_backward(grad_costs, grads_diagonal, ys, xn, yn, V, blank=0
     return _ops.expand_grads(grads_diagonal, ys, xn, yn, grad_costs, V, blank, overwrite=False)
 
 
-def rnnt_loss_compact(xs, ys, xn, yn, blank=0, fastemit_lambda=0.0, required_grad=True):
+def rnnt_loss_compact(xs, ys, xn, yn, blank=0, fastemit_lambda=0.0, required_grad=True, max_frames=None,
+                      max_labels=None):
     """binding.cpp:109-207: (costs (N,), grads (STU,2), loc (STU,) int64) for the compact layout
-    (xs (STU,V) with STU = sum(xn*(yn+1)), ys (sum(yn),)).  Same check order and messages."""
+    (xs (STU,V) with STU = sum(xn*(yn+1)), ys (sum(yn),)).  Same check order and messages.
+    ``max_frames`` / ``max_labels`` (extension): launch bounds the caller vouches for -- no host synchronisation, the
+    op can be captured into a HIP graph; see :func:`warp_rnnt_amd.ops.loss_compact`."""
+    if _native is not None:
+        return _native.rnnt_loss_compact(xs, ys, xn, yn, blank, fastemit_lambda, required_grad,
+                                                 -1 if max_frames is None else int(max_frames),
+                                                 -1 if max_labels is None else int(max_labels))
     for x, name in ((xs, "xs"), (ys, "ys"), (xn, "xn"), (yn, "yn")):
         _check_contiguous(x, name)
     _check_float(xs, "xs")
@@ -121,7 +128,7 @@ def rnnt_loss_compact(xs, ys, xn, yn, blank=0, fastemit_lambda=0.0, required_gra
         raise RuntimeError("xs must have 2 dimensions")
     if xn.size(0) != yn.size(0):
         raise RuntimeError("xn and yn shape must be equal (N,)")
-    costs, grads, loc = _ops.loss_compact(xs, ys, xn, yn, blank, fastemit_lambda, required_grad)
+    costs, grads, loc = _ops.loss_compact(xs, ys, xn, yn, blank, fastemit_lambda, required_grad, max_frames, max_labels)
     if grads is None:
         grads = costs.new_empty((0, 2))    # the reference aliases an unused buffer here
     return costs, grads, loc
@@ -129,6 +136,8 @@ def rnnt_loss_compact(xs, ys, xn, yn, blank=0, fastemit_lambda=0.0, required_gra
 
 def rnnt_loss_compact_backward(grad_cost, grad_xs, cum_lens, loc, V, blank):
     """binding.cpp:209-247: scatter the (STU,2) gradients, scaled per utterance, into (STU,V)."""
+    if _native is not None:
+        return _native.rnnt_loss_compact_backward(grad_cost, grad_xs, cum_lens, loc, int(V), int(blank))
     _check_contiguous(grad_cost, "grad_cost")
     _check_contiguous(grad_xs, "grad_xs")
     _check_contiguous(loc, "loc")

@@ -68,11 +68,12 @@ class RNNTLossCompact(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, log_probs, labels, frames_lengths, labels_lengths, blank=0, fastemit_lambda=0.0,
-                enable_grad: bool = True):
+                enable_grad: bool = True, max_frames=None, max_labels=None):
         costs, pairs_grad, loc = core.rnnt_loss_compact(xs=log_probs, ys=labels, xn=frames_lengths,
                                                         yn=labels_lengths, blank=blank,
                                                         fastemit_lambda=fastemit_lambda,
-                                                        required_grad=enable_grad)
+                                                        required_grad=enable_grad, max_frames=max_frames,
+                                                        max_labels=max_labels)
         if enable_grad:
             rows_per_utt = frames_lengths * (labels_lengths + 1)
             ctx.save_for_backward(pairs_grad, loc, torch.cumsum(rows_per_utt, dim=0, dtype=torch.int32))
@@ -84,7 +85,7 @@ class RNNTLossCompact(torch.autograd.Function):
         pairs_grad, loc, row_ends = ctx.saved_tensors
         dense = core.rnnt_loss_compact_backward(grads_output.contiguous(), pairs_grad, row_ends, loc,
                                                 ctx.vocab, ctx.blank)
-        return (dense,) + (None,) * 6
+        return (dense,) + (None,) * 8
 
 
 def _check_call(average_frames, reduction, blank, gather, labels, frames_lengths, labels_lengths):
@@ -117,7 +118,9 @@ def rnnt_loss(log_probs: torch.FloatTensor,
               blank: int = 0,
               gather: bool = False,
               fastemit_lambda: float = 0.0,
-              compact: bool = False) -> torch.Tensor:
+              compact: bool = False,
+              max_frames: Optional[int] = None,
+              max_labels: Optional[int] = None) -> torch.Tensor:
     """RNN-Transducer negative log-likelihood of a minibatch.
 
     ``log_probs``       fp32, contiguous, on the GPU, already log-softmaxed over the last axis:
@@ -132,13 +135,18 @@ def rnnt_loss(log_probs: torch.FloatTensor,
     ``gather``          run on the 2-channel (blank, label) view of ``log_probs``; same result, the
                         gradient tensor kept for backward is ``V/2`` times smaller.
     ``fastemit_lambda`` FastEmit weight (arXiv:2010.11148): scales the label gradients by ``1+lambda``.
+    ``compact``         the ragged packed layout (the reference's: `__init__.py:109-116`).
+    ``max_frames``, ``max_labels``  (not in the reference; compact only) upper bounds of ``frames_lengths`` /
+                        ``labels_lengths`` the caller vouches for.  With them the compact path reads nothing back
+                        from the device -- no host synchronisation (the reference's has four, this one otherwise one)
+                        and the call can be captured into a HIP graph; a batch that does not fit them gives NaN costs.
     """
     _check_call(average_frames, reduction, blank, gather, labels, frames_lengths, labels_lengths)
 
     if compact:
         wants_grad = log_probs.requires_grad and torch.is_grad_enabled()
         costs = RNNTLossCompact.apply(log_probs.float(), labels, frames_lengths, labels_lengths, blank,
-                                      fastemit_lambda, wants_grad)
+                                      fastemit_lambda, wants_grad, max_frames, max_labels)
     else:
         fn = RNNTLossGather if gather else RNNTLoss
         costs = fn.apply(log_probs, labels, frames_lengths, labels_lengths, blank, fastemit_lambda)

@@ -42,6 +42,8 @@ SYMBOLS = {
     "rnnt_amd_gather": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i]),
     "rnnt_amd_workspace_size_compact": (_sz, [_i, _i64, _i, _i]),
     "rnnt_amd_loss_compact": (_i, [_vp] * 11 + [_i, _i64, _i, _i, _i, _i, _f]),
+    "rnnt_amd_workspace_size_compact_bounded": (_sz, [_i, _i64, _i, _i]),
+    "rnnt_amd_loss_compact_bounded": (_i, [_vp] * 4 + [_i64] + [_vp] * 5 + [_i, _i64, _i, _i, _i, _i, _f]),
     "rnnt_amd_compact_scatter_grads": (_i, [_vp] * 6 + [_i64, _i, _i, _i]),
     "rnnt_amd_compact_offsets": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp]),
     "rnnt_amd_debug_lattice_only": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i]),
@@ -55,7 +57,7 @@ SYMBOLS = {
 }
 
 
-ABI_VERSION = 103   # rnnt_amd_version() of the library these argument lists belong to
+ABI_VERSION = 104   # rnnt_amd_version() of the library these argument lists belong to
 
 
 class RNNTStatusError(RuntimeError):

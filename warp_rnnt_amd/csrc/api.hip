@@ -57,7 +57,7 @@ bool dims_ok(int N, int T, int U) {
 
 extern "C" {
 
-int rnnt_amd_version(void) { return 103; }
+int rnnt_amd_version(void) { return 104; }
 
 int rnnt_amd_set_lattice(int route) { return set_lattice_route(route); }
 
@@ -346,6 +346,55 @@ rnntStatus_t rnnt_amd_loss_compact(rnntStream_t stream, void* workspace, const f
                 Tmax, Umax, 2, 0, fastemit_lambda, cell_offsets};
     if (launch_grads(stream, ga, N, LOAD_SKEWED, grads2 ? WRITE_ROWMAJOR2 : WRITE_SKEWED2) != hipSuccess)
         return RNNT_STATUS_GRADS_BLANK_FAILED;
+    return RNNT_STATUS_SUCCESS;
+}
+
+// The same with the launch bounds supplied by the caller: the offsets are computed here, on the device, and what the
+// host would have checked after reading the maxima back is checked there too (prologue.hip: k_compact_offsets) -- no
+// host synchronisation anywhere, so the call can be captured into a HIP graph.  A batch whose lengths do not fit the
+// bounds, or whose totals are not STU / n_labels, gets NaN costs and zero gradients.
+namespace {
+struct BoundedExtra {
+    int64_t* cell_offsets;   // (N+1,)
+    int64_t* stats;          // (5,): the four of rnnt_amd_compact_offsets + "refused"
+    int* label_offsets;      // (N+1,)
+    int* xn_checked;         // (N,)
+};
+size_t carve_bounded(char* base, size_t off, int N, BoundedExtra* e) {
+    auto take = [&](size_t bytes) { size_t o = off; off += align_up(bytes); return base ? base + o : nullptr; };
+    int64_t* co = reinterpret_cast<int64_t*>(take(((size_t)N + 1) * 8));
+    int64_t* st = reinterpret_cast<int64_t*>(take(5 * 8));
+    int* lo = reinterpret_cast<int*>(take(((size_t)N + 1) * 4));
+    int* xc = reinterpret_cast<int*>(take((size_t)N * 4));
+    if (e) *e = BoundedExtra{co, st, lo, xc};
+    return off;
+}
+}  // namespace
+
+size_t rnnt_amd_workspace_size_compact_bounded(int N, int64_t STU, int Tmax, int Umax) {
+    const size_t base = rnnt_amd_workspace_size_compact(N, STU, Tmax, Umax);
+    if (base == 0) return 0;
+    return carve_bounded(nullptr, base, N, nullptr);
+}
+
+rnntStatus_t rnnt_amd_loss_compact_bounded(rnntStream_t stream, void* workspace, const float* xs, const int* ys,
+                                           int64_t n_labels, const int* xn, const int* yn, float* costs, float* grads2,
+                                           int64_t* loc, int N, int64_t STU, int Tmax, int Umax, int V, int blank,
+                                           float fastemit_lambda) {
+    if (!compact_dims_ok(N, STU, Tmax, Umax) || !workspace || Tmax < 1 || Umax < 1 || n_labels < 0)
+        return RNNT_STATUS_INVALID_ARGUMENT;
+    if (reinterpret_cast<uintptr_t>(workspace) % ALIGN) return RNNT_STATUS_INVALID_ARGUMENT;
+    if (N == 0) return RNNT_STATUS_SUCCESS;
+    BoundedExtra e;
+    carve_bounded(static_cast<char*>(workspace), rnnt_amd_workspace_size_compact(N, STU, Tmax, Umax), N, &e);
+    const CompactBounds b{e.xn_checked, STU, n_labels, Tmax, Umax};
+    if (launch_compact_offsets(stream, xn, yn, N, e.cell_offsets, e.label_offsets, e.stats, &b) != hipSuccess)
+        return RNNT_STATUS_PROLOGUE_FAILED;
+    const rnntStatus_t st = rnnt_amd_loss_compact(stream, workspace, xs, ys, e.xn_checked, yn, e.cell_offsets,
+                                                  e.label_offsets, costs, grads2, loc, N, STU, Tmax, Umax, V, blank,
+                                                  fastemit_lambda);
+    if (st != RNNT_STATUS_SUCCESS) return st;
+    if (launch_zero_if_refused(stream, e.stats + 4, grads2, (size_t)STU) != hipSuccess) return RNNT_STATUS_EXPAND_FAILED;
     return RNNT_STATUS_SUCCESS;
 }
 

@@ -146,6 +146,91 @@ at::Tensor rnnt_loss_gather_backward(const at::Tensor& grad_costs, const at::Ten
     return out;
 }
 
+// ---- the reference's compact native ops (binding.cpp:109-247; pybind names and keywords :255-268) ----
+// (costs (N,), grads (STU,2) -- an empty (0,2) tensor when required_grad is false --, loc (STU,) int64).
+// max_frames / max_labels (an extension: both >= 0, or both -1) are launch bounds the caller vouches for: with them
+// nothing is read back from the device (the reference reads yn.sum(), xn.max(), yn.max() and the last prefix sum: four
+// synchronisations; this op without bounds: one), so the op can sit inside a captured HIP graph; the shape checks that
+// need the sums then happen on the device and a batch that fails them comes back with NaN costs and zero gradients.
+std::tuple<at::Tensor, at::Tensor, at::Tensor> rnnt_loss_compact_forward(const at::Tensor& xs, const at::Tensor& ys,
+                                                                         const at::Tensor& xn, const at::Tensor& yn,
+                                                                         int64_t blank, double fastemit_lambda,
+                                                                         bool required_grad, int64_t max_frames,
+                                                                         int64_t max_labels) {
+    RNNT_CHECK_CONTIGUOUS(xs); RNNT_CHECK_CONTIGUOUS(ys); RNNT_CHECK_CONTIGUOUS(xn); RNNT_CHECK_CONTIGUOUS(yn);
+    RNNT_CHECK_FLOAT(xs); RNNT_CHECK_INT(ys); RNNT_CHECK_INT(xn); RNNT_CHECK_INT(yn);
+    RNNT_CHECK_CUDA(xs); RNNT_CHECK_CUDA(ys); RNNT_CHECK_CUDA(xn); RNNT_CHECK_CUDA(yn);
+    TORCH_CHECK(xs.dim() == 2, "xs must have 2 dimensions");
+    TORCH_CHECK(xn.size(0) == yn.size(0), "xn and yn shape must be equal (N,)");
+    TORCH_CHECK((max_frames < 0) == (max_labels < 0), "max_frames and max_labels go together");
+    const c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(xs.device());
+    const int64_t N = xn.size(0), STU = xs.size(0), V = xs.size(1);
+    TORCH_CHECK(N < (1ll << 31) && V >= 1 && V < (1ll << 31) && blank >= 0 && blank < V,
+                "rnnt_loss status 5 (RNNT_STATUS_INVALID_ARGUMENT): unsupported sizes or blank");
+    const auto fopt = xs.options();
+    at::Tensor costs = at::empty({N}, fopt);
+    at::Tensor loc = at::empty({STU}, fopt.dtype(at::kLong));
+    at::Tensor grads = required_grad ? at::empty({STU, 2}, fopt) : at::empty({0, 2}, fopt);
+    if (N == 0) return {costs, grads, loc};
+    const rnntStream_t stream = current_stream(xs);
+    float* gptr = required_grad ? grads.data_ptr<float>() : nullptr;
+    const int* ysp = ys.numel() ? ys.data_ptr<int>() : nullptr;
+    if (max_frames >= 0) {
+        const int tmax = (int)max_frames, umax = (int)max_labels + 1;
+        TORCH_CHECK(max_frames >= 1 && max_frames < (1ll << 31) && max_labels < (1ll << 31) - 1,
+                    "max_frames >= 1 and max_labels >= 0 expected");
+        const size_t ws_bytes = rnnt_amd_workspace_size_compact_bounded((int)N, STU, tmax, umax);
+        TORCH_CHECK(ws_bytes != 0, "rnnt_loss status 5 (RNNT_STATUS_INVALID_ARGUMENT): unsupported sizes");
+        at::Tensor ws = at::empty({(int64_t)ws_bytes}, fopt.dtype(at::kByte));
+        check_status(rnnt_amd_loss_compact_bounded(stream, ws.data_ptr(), xs.data_ptr<float>(), ysp, ys.numel(),
+                                                   xn.data_ptr<int>(), yn.data_ptr<int>(), costs.data_ptr<float>(), gptr,
+                                                   loc.data_ptr<int64_t>(), (int)N, STU, tmax, umax, (int)V, (int)blank,
+                                                   (float)fastemit_lambda));
+        return {costs, grads, loc};
+    }
+    at::Tensor offs = at::empty({N + 1 + 4}, fopt.dtype(at::kLong));
+    at::Tensor loffs = at::empty({N + 1}, fopt.dtype(at::kInt));
+    check_status(rnnt_amd_compact_offsets(stream, xn.data_ptr<int>(), yn.data_ptr<int>(), (int)N, offs.data_ptr<int64_t>(),
+                                          loffs.data_ptr<int>(), offs.data_ptr<int64_t>() + N + 1));
+    const at::Tensor stats = offs.narrow(0, N + 1, 4).cpu();              // the one host synchronisation
+    const int64_t* st = stats.data_ptr<int64_t>();
+    TORCH_CHECK(ys.numel() == st[1], "ys shape must be equal to (sum(yn), )");
+    TORCH_CHECK(STU == st[0], "xs shape mismatch with (\\sum{xn*(yn+1)}, )");
+    const int tmax = (int)st[2], umax = (int)st[3] + 1;
+    const size_t ws_bytes = rnnt_amd_workspace_size_compact((int)N, STU, tmax, umax);
+    TORCH_CHECK(ws_bytes != 0, "rnnt_loss status 5 (RNNT_STATUS_INVALID_ARGUMENT): unsupported sizes");
+    at::Tensor ws = at::empty({(int64_t)ws_bytes}, fopt.dtype(at::kByte));
+    check_status(rnnt_amd_loss_compact(stream, ws.data_ptr(), xs.data_ptr<float>(), ysp, xn.data_ptr<int>(),
+                                       yn.data_ptr<int>(), offs.data_ptr<int64_t>(), loffs.data_ptr<int>(),
+                                       costs.data_ptr<float>(), gptr, loc.data_ptr<int64_t>(), (int)N, STU, tmax, umax,
+                                       (int)V, (int)blank, (float)fastemit_lambda));
+    return {costs, grads, loc};
+}
+
+// binding.cpp:209-247: the (STU,2) gradients, scaled per utterance, scattered into whole (STU,V) rows
+at::Tensor rnnt_loss_compact_backward(const at::Tensor& grad_cost, const at::Tensor& grad_xs, const at::Tensor& cum_lens,
+                                      const at::Tensor& loc, int64_t V, int64_t blank) {
+    RNNT_CHECK_CONTIGUOUS(grad_cost); RNNT_CHECK_CONTIGUOUS(grad_xs); RNNT_CHECK_CONTIGUOUS(loc);
+    RNNT_CHECK_FLOAT(grad_cost); RNNT_CHECK_FLOAT(grad_xs);
+    TORCH_CHECK(loc.scalar_type() == at::ScalarType::Long, "loc must be a Long tensor");
+    RNNT_CHECK_CUDA(grad_cost); RNNT_CHECK_CUDA(grad_xs); RNNT_CHECK_CUDA(cum_lens); RNNT_CHECK_CUDA(loc);
+    TORCH_CHECK(grad_cost.dim() == 1, "grad_cost must have 1 dimensions");
+    TORCH_CHECK(grad_xs.dim() == 2, "grad must have 2 dimensions");
+    TORCH_CHECK(grad_xs.size(0) == loc.size(0), "grad and loc must be equal in dim=0");
+    TORCH_CHECK(cum_lens.scalar_type() == at::ScalarType::Int && cum_lens.is_contiguous(),
+                "cum_lens must be a contiguous Int tensor");
+    TORCH_CHECK(V >= 1 && V < (1ll << 31) && blank >= 0 && blank < V,
+                "rnnt_loss status 5 (RNNT_STATUS_INVALID_ARGUMENT): blank is not a vocabulary index");
+    const c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(grad_cost.device());
+    const int64_t N = grad_cost.size(0), STU = grad_xs.size(0);
+    at::Tensor out = at::empty({STU, V}, grad_cost.options());
+    if (STU == 0) return out;
+    check_status(rnnt_amd_compact_scatter_grads(current_stream(out), grad_cost.data_ptr<float>(), grad_xs.data_ptr<float>(),
+                                                loc.data_ptr<int64_t>(), cum_lens.data_ptr<int>(), out.data_ptr<float>(),
+                                                STU, (int)N, (int)V, (int)blank));
+    return out;
+}
+
 // the prologue the reference benchmarks next to the loss (benchmark.py:65,70): row-wise log-softmax; out may be x
 at::Tensor log_softmax(const at::Tensor& x, const c10::optional<at::Tensor>& out_opt) {
     RNNT_CHECK_CONTIGUOUS(x); RNNT_CHECK_FLOAT(x); RNNT_CHECK_CUDA(x);
@@ -170,6 +255,12 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
           py::arg("blank") = 0, py::arg("fastemit_lambda") = 0.0, py::arg("want_mismatch") = false);
     m.def("rnnt_loss_gather_backward", &rnnt_loss_gather_backward, py::arg("grad_costs"), py::arg("grads_diagonal"),
           py::arg("ys"), py::arg("xn"), py::arg("yn"), py::arg("V"), py::arg("blank") = 0);
+    // (names and keywords of the reference's module, binding.cpp:255-268)
+    m.def("rnnt_loss_compact", &rnnt_loss_compact_forward, py::arg("xs"), py::arg("ys"), py::arg("xn"),
+          py::arg("yn"), py::arg("blank") = 0, py::arg("fastemit_lambda") = 0.0, py::arg("required_grad") = true,
+          py::arg("max_frames") = -1, py::arg("max_labels") = -1);
+    m.def("rnnt_loss_compact_backward", &rnnt_loss_compact_backward, py::arg("grad_costs"), py::arg("grad_xs"),
+          py::arg("cumSum"), py::arg("loc"), py::arg("V"), py::arg("blank") = 0);
     m.def("log_softmax", &log_softmax, py::arg("x"), py::arg("out") = py::none());
     m.def("library_version", []() { return rnnt_amd_version(); });
 }

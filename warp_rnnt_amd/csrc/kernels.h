@@ -115,8 +115,17 @@ hipError_t launch_gather_compact_rowmajor(hipStream_t stream, const float* xs, c
                                           unsigned blank);
 hipError_t launch_costs_from_betas(hipStream_t stream, const float* betas, const unsigned* mem_pref, const int* xn,
                                    const int* yn, float* costs, int N);
+// launch bounds and tensor sizes the caller vouches for, checked on the device (rnnt_amd_loss_compact_bounded):
+// xn_checked (N,) receives xn, or zeros when any length is outside [1, Tmax] x [0, Umax-1] or the totals differ
+struct CompactBounds {
+    int* xn_checked;
+    int64_t STU, n_labels;
+    int Tmax, Umax;
+};
 hipError_t launch_compact_offsets(hipStream_t stream, const int* xn, const int* yn, int N, int64_t* cell_offs,
-                                  int* label_offs, int64_t* stats);
+                                  int* label_offs, int64_t* stats, const CompactBounds* bounds = nullptr);
+// (stats[4], written only with bounds: 1 = the batch was refused)
+hipError_t launch_zero_if_refused(hipStream_t stream, const int64_t* refused, float* grads2, size_t cells);
 hipError_t launch_gather_compact(hipStream_t stream, const float* xs, const int* ys, const int* xn,
                                  const int* yn, const int64_t* offs, const int* label_offs, float* ws2,
                                  int64_t* loc, int N, int Tmax, int Umax, int V, int blank);

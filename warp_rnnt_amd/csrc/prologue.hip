@@ -14,6 +14,8 @@
 #include <climits>
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -1115,7 +1117,7 @@ hipError_t launch_gather_compact_rowmajor(hipStream_t stream, const float* xs, c
 constexpr int CP_THREADS = 1024;
 __global__ void __launch_bounds__(CP_THREADS)
 k_compact_offsets(const int* __restrict__ xn, const int* __restrict__ yn, int N, int64_t* __restrict__ cell_offs,
-                  int* __restrict__ label_offs, int64_t* __restrict__ stats) {
+                  int* __restrict__ label_offs, int64_t* __restrict__ stats, const CompactBounds bounds) {
     __shared__ int64_t s_cells[CP_THREADS];
     __shared__ int s_labs[CP_THREADS];
     __shared__ int s_tmax[CP_THREADS / WAVE], s_umax[CP_THREADS / WAVE];
@@ -1167,11 +1169,47 @@ k_compact_offsets(const int* __restrict__ xn, const int* __restrict__ yn, int N,
         stats[2] = tm;
         stats[3] = um;
     }
+    if (bounds.xn_checked) {
+        // Caller-supplied launch bounds (no read-back of the maxima): what the host would have checked after its
+        // synchronisation is checked here.  One length out of range, or totals that are not the tensors' sizes, make
+        // every offset meaningless, so the whole batch is refused: lengths of 0 frames go to the kernels, which report
+        // cost = NaN and touch nothing.
+        __shared__ int s_bad;
+        if (tid == 0) s_bad = 0;
+        __syncthreads();
+        bool bad = false;
+        for (int n = lo; n < hi; ++n) {
+            const int x = xn[n], y = yn[n];
+            bad |= x < 1 || y < 0 || x > bounds.Tmax || y + 1 > bounds.Umax;
+        }
+        if (tid == CP_THREADS - 1) bad |= s_cells[tid] != bounds.STU || (int64_t)s_labs[tid] != bounds.n_labels;
+        if (bad) atomicOr(&s_bad, 1);
+        __syncthreads();
+        const bool refuse = s_bad != 0;
+        for (int n = lo; n < hi; ++n) bounds.xn_checked[n] = refuse ? 0 : xn[n];
+        if (tid == 0) stats[4] = refuse ? 1 : 0;
+    }
+}
+
+// behind a bounded compact call: a refused batch owns no cells the kernels could have written, so its (STU,2)
+// gradients are zeroed here; returns at once otherwise (one flag read per thread)
+__global__ void __launch_bounds__(256)
+k_zero_if_refused(const int64_t* __restrict__ refused, float2* __restrict__ g2, size_t cells) {
+    if (*refused == 0) return;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < cells; i += (size_t)gridDim.x * 256) g2[i] = make_float2(0.f, 0.f);
+}
+
+hipError_t launch_zero_if_refused(hipStream_t stream, const int64_t* refused, float* grads2, size_t cells) {
+    if (!grads2 || cells == 0) return hipSuccess;
+    const unsigned blocks = (unsigned)std::min<size_t>(1024, (cells + 255) / 256);
+    k_zero_if_refused<<<blocks, 256, 0, stream>>>(refused, reinterpret_cast<float2*>(grads2), cells);
+    return hipGetLastError();
 }
 
 hipError_t launch_compact_offsets(hipStream_t stream, const int* xn, const int* yn, int N, int64_t* cell_offs,
-                                  int* label_offs, int64_t* stats) {
-    k_compact_offsets<<<1, CP_THREADS, 0, stream>>>(xn, yn, N, cell_offs, label_offs, stats);
+                                  int* label_offs, int64_t* stats, const CompactBounds* bounds) {
+    const CompactBounds none{nullptr, 0, 0, 0, 0};
+    k_compact_offsets<<<1, CP_THREADS, 0, stream>>>(xn, yn, N, cell_offs, label_offs, stats, bounds ? *bounds : none);
     return hipGetLastError();
 }
 

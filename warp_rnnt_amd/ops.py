@@ -140,19 +140,38 @@ def gather(log_probs, labels, blank=0):
     return out
 
 
-def loss_compact(xs, ys, xn, yn, blank=0, fastemit_lambda=0.0, required_grad=True):
+def loss_compact(xs, ys, xn, yn, blank=0, fastemit_lambda=0.0, required_grad=True, max_frames=None, max_labels=None):
     """Compact (ragged packed) layout: xs (STU,V), ys (sum yn,), xn/yn (N,).
-    Returns (costs (N,), grads (STU,2) or None, loc (STU,) int64).  One host synchronisation
-    (max lengths for the launch geometry + the shape checks; the reference does four)."""
+    Returns (costs (N,), grads (STU,2) or None, loc (STU,) int64).
+
+    Without bounds: one host synchronisation (the maxima of the lengths size the launches, and the shape checks of the
+    reference's binding need the sums; the reference does four).  With ``max_frames >= max(xn)`` and ``max_labels >=
+    max(yn)`` supplied by the caller: none -- offsets, maxima and checks stay on the device (``rnnt_amd_loss_compact_
+    bounded``), the call can be captured into a HIP graph; a batch that does not fit the bounds or the tensors' sizes
+    comes back with NaN costs and zero gradients instead of an exception."""
     L = _lib.load()
     dev = xs.device
     N = xn.shape[0]
     STU, V = xs.shape
+    if (max_frames is None) != (max_labels is None):
+        raise ValueError("max_frames and max_labels go together")
     with torch.cuda.device(dev):
         costs = torch.empty((N,), dtype=torch.float32, device=dev)
         loc = torch.empty((STU,), dtype=torch.int64, device=dev)
         grads = torch.empty((STU, 2), dtype=torch.float32, device=dev) if required_grad else None
         if N == 0:
+            return costs, grads, loc
+        if max_frames is not None:
+            tmax, umax = int(max_frames), int(max_labels) + 1
+            if tmax < 1 or umax < 1:
+                raise ValueError("max_frames >= 1 and max_labels >= 0 expected")
+            ws_bytes = L.rnnt_amd_workspace_size_compact_bounded(N, STU, tmax, umax)
+            if ws_bytes == 0:
+                raise RuntimeError("rnnt_loss status 5 (RNNT_STATUS_INVALID_ARGUMENT): unsupported sizes")
+            ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
+            _check(L.rnnt_amd_loss_compact_bounded(_stream(dev), ws.data_ptr(), xs.data_ptr(), _ptr(ys), ys.numel(),
+                                                   xn.data_ptr(), yn.data_ptr(), costs.data_ptr(), _ptr(grads),
+                                                   loc.data_ptr(), N, STU, tmax, umax, V, blank, float(fastemit_lambda)))
             return costs, grads, loc
         offs = torch.empty((N + 1 + 4,), dtype=torch.int64, device=dev)    # offsets + the 4 stats
         loffs = torch.empty((N + 1,), dtype=torch.int32, device=dev)
