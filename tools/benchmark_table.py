@@ -31,26 +31,26 @@ README_MS = {   # README.md:38-53  (gather=False, gather=True) on RTX 2070 Super
 }
 
 
-def run_benchmark(loss, E, N, T, U, V, random_length=False, warmup=1):
+def run_benchmark(loss, E, N, T, U, V, random_length=False, warmup=1, device="cuda:0"):
     torch.manual_seed(N)
     elapsed = 0.0
     for i in range(E + warmup):
-        xs = torch.randn((N, T, U, V), dtype=torch.float32, device="cuda", requires_grad=True)
-        ys = torch.randint(1, V, (N, U - 1), dtype=torch.int, device="cuda")
+        xs = torch.randn((N, T, U, V), dtype=torch.float32, device=device, requires_grad=True)
+        ys = torch.randint(1, V, (N, U - 1), dtype=torch.int, device=device)
         if random_length:
-            xn = torch.randint(T // 2, T + 1, (N,), dtype=torch.int, device="cuda")
-            yn = torch.randint(U // 2, U, (N,), dtype=torch.int, device="cuda")
+            xn = torch.randint(T // 2, T + 1, (N,), dtype=torch.int, device=device)
+            yn = torch.randint(U // 2, U, (N,), dtype=torch.int, device=device)
             xn = xn + T - xn.max()
             yn = yn + U - 1 - yn.max()
         else:
-            xn = torch.ones((N,), dtype=torch.int, device="cuda") * T
-            yn = torch.ones((N,), dtype=torch.int, device="cuda") * (U - 1)
+            xn = torch.ones((N,), dtype=torch.int, device=device) * T
+            yn = torch.ones((N,), dtype=torch.int, device=device) * (U - 1)
         if hasattr(loss, "prepare"):      # data layout work that is not part of the loss (untimed)
             xs, ys = loss.prepare(xs, ys, xn, yn)
-        torch.cuda.synchronize()
+        torch.cuda.synchronize(device)
         t = timer()
         costs = loss(xs, ys, xn, yn)
-        torch.cuda.synchronize()
+        torch.cuda.synchronize(device)
         if i >= warmup:
             elapsed += timer() - t
         del xs, ys, xn, yn, costs
@@ -60,6 +60,7 @@ def run_benchmark(loss, E, N, T, U, V, random_length=False, warmup=1):
 def main():
     p = argparse.ArgumentParser(description="Benchmark RNN-T loss implementation")
     p.add_argument("--loss", type=str, required=True)
+    p.add_argument("--device", type=int, default=0, help="GPU index (benchmark.py:57)")
     p.add_argument("--random_length", action="store_true")
     p.add_argument("--warmup", type=int, default=1)
     p.add_argument("--markdown", type=str, default=None)
@@ -69,6 +70,8 @@ def main():
     a = p.parse_args()
     grid = [tuple(int(x) for x in g.split(",")) for g in a.grid.split(";")] if a.grid else GRID
     batches = [int(x) for x in a.batches.split(",")] if a.batches else BATCHES
+    device = torch.device("cuda", a.device)
+    torch.cuda.set_device(device)
     import warp_rnnt
     from warp_rnnt_amd import ops
     from warp_rnnt_amd.fused import rnnt_loss_from_logits
@@ -104,7 +107,7 @@ def main():
             print(f"T={T}\tU={U}\tV={V}\tN={N}\t", end="", flush=True)
             try:
                 ms = run_benchmark(run_loss, E=E, N=N, T=T, U=U, V=V, random_length=a.random_length,
-                                   warmup=a.warmup)
+                                   warmup=a.warmup, device=device)
                 print(f"time={ms:.2f}")
                 ref = README_MS.get((T, U, V), {}).get(N, ("n/a", "n/a"))[col]     # None = out of memory there
                 rows.append((T, U, V, N, ms, ref))

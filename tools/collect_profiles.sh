@@ -3,7 +3,7 @@
 # Copy the summaries into profiles/ afterwards with `python tools/summarise_profiles.py $TAG`.
 #   --pmc passes are separate from each other and never combined with other trace domains.
 set -u
-TAG=${1:-r03}
+TAG=${1:-r04}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
@@ -12,7 +12,7 @@ python $R/bench.py > $OUT/bench_c4.json 2> $OUT/bench_c4.err
 python $R/bench.py --config c2 --steps 500 --warmup 20 > $OUT/bench_c2.json 2>> $OUT/bench.err
 python $R/bench.py --config c3 --steps 100 > $OUT/bench_c3.json 2>> $OUT/bench.err
 python $R/bench.py --config c5 --steps 5 --warmup 1 --no-cpu-baseline > $OUT/bench_c5.json 2>> $OUT/bench.err
-RNNT_LATTICE=logdomain python $R/bench.py --no-cpu-baseline > $OUT/bench_c4_logdomain_lattice.json 2>> $OUT/bench.err
+RNNT_LATTICE=pd python $R/bench.py --no-cpu-baseline > $OUT/bench_c4_pd_lattice.json 2>> $OUT/bench.err
 rocprofv3 --kernel-trace --stats -d $OUT/stats_c4 -o c4 -- python $R/bench.py --steps 50 --warmup 5 --no-cpu-baseline > $OUT/bench_c4_profiled.json 2>/dev/null
 rocprofv3 --kernel-trace --stats -d $OUT/stats_c3 -o c3 -- python $R/bench.py --config c3 --steps 50 --warmup 5 --no-cpu-baseline > /dev/null 2>&1
 rocprofv3 --kernel-trace --stats -d $OUT/stats_c2 -o c2 -- python $R/bench.py --config c2 --steps 100 --warmup 5 --no-cpu-baseline > /dev/null 2>&1
@@ -49,18 +49,26 @@ rm -f $OUT/parity_errors.json
 RNNT_PARITY_TABLE=$OUT/parity_errors.json RNNT_PARITY_BUILD="shipped" python -m pytest tests/test_gpu_baseline_sizes.py -q > $OUT/parity_default.log 2>&1
 # (the libm build of the log-domain lattice -- the reference's own log1pf(expf()) -- is in profiles/r02_parity_errors.json:
 #  within 5e-4 of the shipped log-domain route at every size)
-# lattice kernel alone, both arithmetic domains
-for sh in 16,1500,300 16,1500,64 16,1500,128 16,1500,512 8,3000,500 24,1500,300 32,1500,300 64,1500,300 16,700,100 16,400,100 16,150,40; do
-  for v in pd logdomain; do
-    RNNT_LATTICE=$v python tools/lattice_probe.py --shape $sh main: 2>&1 | grep median | sed "s/^main */N,T,U=$sh lattice=$v  /"
-  done
-done > $OUT/lattice_probe.txt
+# lattice kernels alone: probability domain, log domain on one workgroup per sweep / per column block
+python tools/lattice_routes.py > $OUT/lattice_routes.txt 2>&1
+# the reference-named C entry points the way the reference's binding calls them
+python tools/cabi_probe.py c2 c4 2>&1 | grep -v amdgpu > $OUT/cabi_probe.txt
+# interval-by-interval timeline of the distributed log-domain kernel (diagnostics build, if it travelled)
+if [ -f tools/_probe/wdstats/lib.so ]; then
+  python tools/wd_trace.py 16 1500 300 2>&1 | grep -v amdgpu > $OUT/wd_trace_c4.txt
+fi
 (python tools/graph_probe.py 16 150 40 28 0 1000; python tools/graph_probe.py 16 1500 300 50 1) 2>&1 | grep "N=" > $OUT/graph_probe.txt
 tools/ubench/pd_steps > $OUT/ubench_pd_steps.txt 2>&1
 python tools/host_overhead.py 2>&1 | grep -v amdgpu > $OUT/host_overhead.txt
 (echo "== ctypes fallback"; WARP_RNNT_AMD_NO_NATIVE_BINDING=1 python tools/host_overhead.py 2>&1 | grep -v amdgpu) >> $OUT/host_overhead.txt
 python $R/bench.py --no-cpu-baseline --rccl-group > $OUT/bench_c4_rccl_group.json 2>> $OUT/bench.err
-for l in warp-rnnt-gather warp-rnnt-fused warp-rnnt-compact; do
+for l in warp-rnnt warp-rnnt-gather warp-rnnt-fused warp-rnnt-compact; do
   timeout 200 python $R/tools/benchmark_table.py --loss $l --markdown $OUT/table_$l.md > $OUT/table_$l.log 2>&1
 done
+ls $OUT
+# shape map off BASELINE's five points (one kernel-trace pass)
+mkdir -p $OUT/shape_map
+(cd /tmp && rocprofv3 --kernel-trace --output-format csv -d $OUT/shape_map -o map -- python $R/tools/shape_map.py run > $OUT/shape_map/manifest.json 2> $OUT/shape_map/err.txt)
+python tools/shape_map.py report $OUT/shape_map/map_kernel_trace.csv $OUT/shape_map/manifest.json > $OUT/shape_map.md 2>> $OUT/bench.err
+rm -f $OUT/shape_map/map_kernel_trace.csv
 ls $OUT
