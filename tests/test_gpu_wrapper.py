@@ -112,7 +112,14 @@ def test_non_default_stream_and_device_guard():
     np.testing.assert_allclose(tot.item(), ref["costs"].sum(), rtol=1e-5)
 
 
-@pytest.mark.parametrize("N,Tm,Um,V", [(3, 30, 12, 50), (2, 9, 5, 5000), (2, 11, 70, 7), (2, 6, 4, 1030)])
+# V % 32 == 0, and V % 4 == 0 above 256: the rows-in-registers fused gather (prologue.hip: k_lsm_rows, 8 ... 64 lanes per
+# row, ragged last float4; k_lsm_rows_diag for V = 32, 64 and its T < 16 fallback); the others stay on the LDS tiles
+@pytest.mark.parametrize("N,Tm,Um,V", [(3, 30, 12, 50), (2, 9, 5, 5000), (2, 11, 70, 7), (2, 6, 4, 1030),
+                                       (3, 40, 21, 128), (2, 33, 9, 64), (2, 21, 12, 32), (2, 17, 14, 80),
+                                       (2, 17, 14, 96), (2, 19, 8, 160), (2, 19, 8, 192), (2, 19, 8, 256),
+                                       (2, 13, 8, 200), (2, 9, 20, 128), (2, 30, 35, 64),
+                                       (2, 21, 9, 34), (2, 21, 9, 66), (2, 15, 9, 130), (2, 11, 7, 258), (2, 9, 5, 510),
+                                       (2, 9, 5, 514), (2, 9, 5, 1000)])
 def test_fused_from_logits_forward_backward(N, Tm, Um, V):
     """rnnt_loss_from_logits == rnnt_loss(torch.log_softmax(logits), gather=True) incl. d/d logits
     (small-V, large-V and generic log-softmax kernels)."""
@@ -128,7 +135,8 @@ def test_fused_from_logits_forward_backward(N, Tm, Um, V):
     l2 = rnnt_loss_from_logits(z2, T(labels), T(xn), T(yn), fastemit_lambda=0.01)
     l2.backward(T(up))
     np.testing.assert_allclose(l2.detach().cpu().numpy(), l1.detach().cpu().numpy(), rtol=1e-5)
-    np.testing.assert_allclose(z2.grad.cpu().numpy(), z1.grad.cpu().numpy(), atol=2e-5)
+    # (two fp32 evaluations of one function: torch's log-softmax and its backward against the fused kernels)
+    np.testing.assert_allclose(z2.grad.cpu().numpy(), z1.grad.cpu().numpy(), atol=3e-5, rtol=3e-5)
     # against exact arithmetic: dz = g - softmax * sum(g) with the fp64 oracle's g
     from oracle import transduce_np
     lp64 = transduce_np.log_softmax(logits)

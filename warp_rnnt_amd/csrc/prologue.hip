@@ -502,6 +502,188 @@ __global__ void __launch_bounds__(256) k_lsm_regs(const float* __restrict__ x, f
     }
 }
 
+// ---------------------------------------------------------------------------
+// Rows in registers, L lanes per row (round 4; fused gather, V a multiple of 4).  Every row is 16-byte aligned, so
+// its L lanes load Q4 float4 each straight from HBM (a row instruction reads L*16 contiguous bytes: whole 128-byte lines
+// from L = 8 on), reduce with L-wide butterflies and never touch LDS; a wave carries UN passes of 64/L rows, all loads
+// issued before the first use.  The LDS-staged kernel spends 333 VALU instructions per wave on the same work at V = 128
+// (run-time column loops, two LDS reads per element; SQ counters: the vector ALUs 67 % busy at 4.7 TB/s,
+// profiles/r04_lsm_rows_ab.txt), this one about 150.  Fused gather only: as the plain log-softmax it runs at the rate of
+// the kernels that serve it now (V = 160 ... 600: 5.5-5.7 TB/s either way), so that mode is not instantiated.
+//   One lane per row (all rows of the wave in one go: the index arithmetic of map_cell is paid once per
+//   wave) fetches the row's blank and label logits again -- the wave has just read those lines -- and stores the pair.
+// ---------------------------------------------------------------------------
+// all-reduce over aligned groups of L lanes on DPP (quad permutes, then the mirrors: once every lane of a quad holds the
+// quad's value, reversing 8 / 16 lanes swaps whole quads / halves), lane ^ 16 on ds_swizzle, lane ^ 32 on a permute
+template <int L, bool MAX> __device__ __forceinline__ float lsm_group_reduce(float v) {
+#define LSM_STEP(w) v = MAX ? fmaxf(v, (w)) : v + (w)
+    if constexpr (L >= 2) LSM_STEP(lsm_dpp<0xB1>(v));
+    if constexpr (L >= 4) LSM_STEP(lsm_dpp<0x4E>(v));
+    if constexpr (L >= 8) LSM_STEP(lsm_dpp<0x141>(v));
+    if constexpr (L >= 16) LSM_STEP(lsm_dpp<0x140>(v));
+    if constexpr (L >= 32) LSM_STEP(lsm_swz16(v));
+    if constexpr (L >= 64) LSM_STEP(__shfl_xor(v, 32, WAVE));
+#undef LSM_STEP
+    return v;
+}
+
+// passes per wave: two for the 8-lane rows (V <= 128: 16 rows = 8 KB per wave at V = 128), one above (V = 256 ... 1024:
+// 299 / 998 us against 306 / 1057 with two, profiles/r04_lsm_rows_ab.txt)
+template <int L> struct RowsShape {
+    static constexpr int UN = L <= 8 ? 2 : 1;
+    static constexpr int RW = WAVE / L;            // rows per pass
+    static constexpr int RPW = RW * UN;            // rows per wave
+};
+
+// loads (all passes first), row maxima and log-sums of the rows at src[p] (one pointer per lane and pass: the lane's
+// first float4 of its row)
+template <int L, int Q, int MODE>
+__device__ __forceinline__ void lsm_rows_stats(const float* const (&src)[RowsShape<L>::UN], bool last_ok,
+                                               float (&mx)[RowsShape<L>::UN], float (&ls)[RowsShape<L>::UN]) {
+    constexpr int UN = RowsShape<L>::UN, VEC = 4;
+    const float ninf = -__builtin_inff();
+    const unsigned last_off = last_ok ? (Q - 1) * L : 0;   // a last float4 past the row: re-read the first, made -inf
+    float v[UN][Q][VEC];
+#pragma unroll
+    for (int p = 0; p < UN; ++p) {
+#pragma unroll
+        for (int i = 0; i < Q; ++i) {
+            const unsigned off = i < Q - 1 ? i * L : last_off;
+            const float4 t = RNNT_LSM_LOAD(reinterpret_cast<const float4*>(src[p]) + off);
+            v[p][i][0] = t.x; v[p][i][1] = t.y; v[p][i][2] = t.z; v[p][i][3] = t.w;
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < UN; ++p)
+#pragma unroll
+        for (int e = 0; e < VEC; ++e)
+            if (!last_ok) v[p][Q - 1][e] = ninf;
+#pragma unroll
+    for (int p = 0; p < UN; ++p) {
+        float m = ninf;
+#pragma unroll
+        for (int i = 0; i < Q; ++i)
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) m = fmaxf(m, v[p][i][e]);
+        m = lsm_group_reduce<L, true>(m);
+        const float mb = -m * LOG2E;
+        float s = 0.0f;
+#pragma unroll
+        for (int i = 0; i < Q; ++i)
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) s += __builtin_amdgcn_exp2f(__builtin_fmaf(v[p][i][e], LOG2E, mb));
+        s = lsm_group_reduce<L, false>(s);
+        mx[p] = m;
+        ls[p] = __builtin_amdgcn_logf(s) * LN2;
+    }
+}
+
+// lane l < RPW picks up the statistics of row l of the wave: first lane of group l % RW, pass l / RW
+template <int L>
+__device__ __forceinline__ void lsm_rows_stats_of_lane(int lane, const float (&mx)[RowsShape<L>::UN],
+                                                       const float (&ls)[RowsShape<L>::UN], float& m, float& lg) {
+    constexpr int UN = RowsShape<L>::UN, RW = RowsShape<L>::RW;
+    const int srcl = (lane % RW) * L;
+    m = 0.0f;
+    lg = 0.0f;
+#pragma unroll
+    for (int p = 0; p < UN; ++p) {
+        const float mp = __shfl(mx[p], srcl, WAVE), lp = __shfl(ls[p], srcl, WAVE);
+        if (lane / RW == p) { m = mp; lg = lp; }
+    }
+}
+
+// consecutive rows per wave
+template <int L, int Q>
+__global__ void __launch_bounds__(256)
+k_lsm_rows(const float* x, float* out, const int* __restrict__ labels, int64_t rows, int V, int T, int U, int blank) {
+    constexpr int MODE = LSM_GATHER, VEC = 4;
+    constexpr int UN = RowsShape<L>::UN, RW = RowsShape<L>::RW, RPW = RowsShape<L>::RPW;
+    const int lane = threadIdx.x & 63, h = lane % L, rr = lane / L;
+    // wave-uniform values kept in scalar registers (the 64-bit row arithmetic runs on the scalar unit)
+    const int64_t row0 = ((int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6)) * RPW;
+    const bool last_ok = (h + (Q - 1) * L) * VEC < V;   // the lane's last float4 is part of the row
+    const bool whole = row0 + RPW <= rows;              // (uniform) every row of this wave exists
+    const float* const wave_src = x + row0 * V;
+    const unsigned lane_off = (unsigned)rr * (unsigned)V + (unsigned)h * VEC;      // floats inside a pass
+    // lane l < RPW owns the pair of row row0 + l.  Its two logits are requested FIRST, next to the row loads that bring
+    // the same lines (asked for after the rows have streamed through, they are fetched a second time: forward 252 vs 216
+    // us at V = 128, profiles/r04_lsm_rows_ab.txt)
+    CellMap cm = {0, 0, 0};
+    float xb = 0.0f, xl = 0.0f;
+    const bool own = lane < RPW && row0 + lane < rows;
+    if (own) {
+        cm = map_cell((size_t)(row0 + lane), labels, T, U, V, blank);
+        const float* xr = x + (row0 + lane) * V;
+        xb = xr[blank];
+        xl = xr[cm.label];
+    }
+    const float* src[UN];
+#pragma unroll
+    for (int p = 0; p < UN; ++p) {
+        src[p] = wave_src + (size_t)(p * RW) * V + lane_off;
+        // (rows past the end of the tensor -- last wave only -- re-read the last row and are dropped at the stores)
+        if (!whole && row0 + p * RW + rr >= rows) src[p] = x + (rows - 1) * V + h * VEC;
+    }
+    float mx[UN], ls[UN];
+    lsm_rows_stats<L, Q, MODE>(src, last_ok, mx, ls);
+    float m, lg;
+    lsm_rows_stats_of_lane<L>(lane, mx, ls, m, lg);
+#ifdef RNNT_LSM_ROWS_PROBE_LINEAR_STORE      // timing probe only (wrong layout): what the scattered 8-byte stores cost
+    if (own) reinterpret_cast<float2*>(out)[row0 + lane] = make_float2((xb - m) - lg, (xl - m) - lg);
+#else
+    if (own) reinterpret_cast<float2*>(out)[cm.sk] = make_float2((xb - m) - lg, (xl - m) - lg);
+#endif
+}
+
+// Along the diagonals (rows that are one or two whole 128-byte lines: V = 32, 64; T >= 16): a wave takes the 16 cells
+// (t' - k mod T, u0 + k), k = 0 ... 15 -- one run of 16 consecutive pairs of the diagonal-major plane, stored as one
+// 128-byte piece -- instead of 16 consecutive rows, whose pairs land 8 bytes each in 16 different lines (counters: 32
+// bytes written per pair; with the pairs stored linearly the kernel is 12-17 us of 145 faster at V = 128, N*T*U = 1.6 M).
+// V = 32 / 64: forward 96.5 / 134 us against 102 / 144; from V = 96 on the scattered rows cost what the stores save (174
+// vs 177, 199 vs 193: consecutive rows kept there).  No index division: grid = (T / 4 rounded up, column blocks of 16, N).
+template <int Q>
+__global__ void __launch_bounds__(256)
+k_lsm_rows_diag(const float* x, float* out, const int* __restrict__ labels, int V, int T, int U, int blank) {
+    constexpr int L = 8, VEC = 4, MODE = LSM_GATHER;
+    constexpr int UN = RowsShape<L>::UN, RW = RowsShape<L>::RW, RPW = RowsShape<L>::RPW;
+    static_assert(RPW == 16, "one run of 16 pairs per wave");
+    const int lane = threadIdx.x & 63, h = lane % L, rr = lane / L;
+    const int tp = (int)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (tp >= T) return;
+    const int u0 = (int)blockIdx.y * RPW, n = (int)blockIdx.z;
+    const bool last_ok = (h + (Q - 1) * L) * VEC < V;
+    const size_t plane = (size_t)n * T;            // frames in front of this utterance
+    // the pair of cell k = lane (lane < 16), requested first
+    float xb = 0.0f, xl = 0.0f;
+    const bool own = lane < RPW && u0 + lane < U;
+    if (own) {
+        const int u = u0 + lane;
+        int t = tp - lane;
+        t += t < 0 ? T : 0;
+        const int lab = (u < U - 1) ? safe_label(labels[(size_t)n * (U - 1) + u], V, blank) : blank;
+        const float* xr = x + ((plane + t) * U + u) * V;
+        xb = xr[blank];
+        xl = xr[lab];
+    }
+    const float* src[UN];
+#pragma unroll
+    for (int p = 0; p < UN; ++p) {
+        const int k = p * RW + rr;
+        const int u = min(u0 + k, U - 1);          // (columns past the plane re-read the last one and are dropped)
+        int t = tp - k;
+        t += t < 0 ? T : 0;
+        src[p] = x + ((plane + t) * U + u) * V + h * VEC;
+    }
+    float mx[UN], ls[UN];
+    lsm_rows_stats<L, Q, MODE>(src, last_ok, mx, ls);
+    float m, lg;
+    lsm_rows_stats_of_lane<L>(lane, mx, ls, m, lg);
+    int r = tp + u0;
+    r = r >= T ? r % T : r;
+    if (own) reinterpret_cast<float2*>(out)[(plane + r) * U + u0 + lane] = make_float2((xb - m) - lg, (xl - m) - lg);
+}
+
 // rows per group for k_lsm_regs, or 0 when the kernel does not fit V: the largest KR <= 4 with KR*V a multiple of 4 and
 // KR*V/4 <= 32 lanes, if it keeps at least 20 of the 32 lanes of a half busy
 static int lsm_regs_rows_per_group(int V) {
@@ -559,6 +741,43 @@ static hipError_t dispatch_lsm(hipStream_t stream, const float* x, float* out, c
             if (th == 192 && nvec * 100 >= th * 94) LGR(192, 1)
             if (th == 256 && nvec * 100 >= th * 94) LGR(256, 1)
 #undef LGR
+        }
+    }
+    if constexpr (MODE == LSM_GATHER) {
+        // Rows in registers, L lanes per row, where the rows are whole 128-byte lines (V % 32 == 0: 32 ... 1024) or long
+        // enough for a row instruction (32 / 64 lanes x 16 bytes) not to mind where the lines start (V % 4 == 0 above
+        // 256).  Forward of the fused entry, N=32, T=500, U=100, us, this kernel / LDS tiles (tools/fused_rate.py,
+        // profiles/r04_lsm_rows_ab.txt): V=32 97 / 158, 64 134 / 170, 96 174 / 178, 128 191-205 / 211-225, 160 260 / 284,
+        // 256 306-321 / 353-359, 400 505 / 586, 512 622 / 655, 600 725 / 901, 800 824 / 1125, 1000 1052 / 1312, 1024 1057 /
+        // 1241; not where an 8- or 16-lane row instruction straddles lines (V=100: 236 / 187, 132: 281 / 257, 200: 327 /
+        // 323) and not with float2 rows for V % 4 == 2 (V=50: 169 / 132 -- c4's lattice: 664 / 465).
+        // (RNNT_LSM_NO_ROWS=1: the LDS-staged kernel, for A/B runs; RNNT_LSM_NO_DIAG=1: consecutive rows per wave for
+        //  every V; RNNT_LSM_ROWS_ANY=1: this kernel for every V % 4 == 0)
+        static const bool no_rows = getenv("RNNT_LSM_NO_ROWS") != nullptr;
+        static const bool no_diag = getenv("RNNT_LSM_NO_DIAG") != nullptr;
+        static const bool rows_any = getenv("RNNT_LSM_ROWS_ANY") != nullptr;
+        if (aligned && !no_rows && V % 4 == 0 && V >= 32 && V <= 1024 && (V % 32 == 0 || V > 256 || rows_any)) {
+            int L = 8;
+            while (L < 64 && L * 16 < V) L <<= 1;
+            const int q = (V / 4 + L - 1) / L;         // 1 ... 4
+            const int64_t N = rows / ((int64_t)T * U), nub = (U + 15) / 16;
+            if (V <= 64 && V % 32 == 0 && T >= 16 && !no_diag && N <= 65535 && nub <= 65535) {
+                const dim3 grid((unsigned)((T + 3) / 4), (unsigned)nub, (unsigned)N);
+                if (q == 1) k_lsm_rows_diag<1><<<grid, 256, 0, stream>>>(x, out, labels, V, T, U, blank);
+                else k_lsm_rows_diag<2><<<grid, 256, 0, stream>>>(x, out, labels, V, T, U, blank);
+                return hipGetLastError();
+            }
+            const int64_t rpw = L <= 8 ? 2 * (WAVE / L) : WAVE / L;       // RowsShape<L>::RPW
+            const int64_t grid = (rows + 4 * rpw - 1) / (4 * rpw);
+            if (grid < ((int64_t)1 << 31)) {
+#define LSM_ROWS(LL, QQ) \
+    if (L == LL && q == QQ) k_lsm_rows<LL, QQ><<<(unsigned)grid, 256, 0, stream>>>(x, out, labels, rows, V, T, U, blank);
+#define LSM_ROWS_L(LL) LSM_ROWS(LL, 1) LSM_ROWS(LL, 2) LSM_ROWS(LL, 3) LSM_ROWS(LL, 4)
+                LSM_ROWS_L(8) LSM_ROWS_L(16) LSM_ROWS_L(32) LSM_ROWS_L(64)
+#undef LSM_ROWS_L
+#undef LSM_ROWS
+                return hipGetLastError();
+            }
         }
     }
     if (aligned && V <= 1024) {
