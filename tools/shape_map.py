@@ -9,7 +9,9 @@ Two steps (the second needs no GPU):
 `run` walks the shapes; for each it runs three entry points a few times -- log_softmax + rnnt_loss(gather=True)
 (the reference's protocol, benchmark.py:62-70), the fused rnnt_loss_from_logits, and (ragged lengths)
 rnnt_loss(compact=True) -- separated by marker fills whose grid size is unique, and prints a manifest.  `report`
-cuts the kernel trace at the markers and prices every kernel with SURVEY.md 8(d)'s algorithmic bytes.
+cuts the kernel trace at the markers and prices every kernel with SURVEY.md 8(d)'s algorithmic bytes; the gathers -- two
+dwords out of every 4V-byte row -- are priced a second time on the 128-byte lines those dwords live in (counted exactly in
+`run`), the unit the memory system moves.
 """
 import csv
 import json
@@ -39,6 +41,14 @@ def lengths(torch, N, T, U, ragged, seed):
     return xn, yn
 
 
+def gather_line_bytes(torch, row_index, labels_of_cell, V):
+    """128-byte lines holding the blank (column 0) or the label logit of the rows `row_index` (row r starts at byte
+    4 V r), plus the 8 bytes written per cell."""
+    off = row_index.to(torch.int64) * (V * 4)
+    lines = torch.unique(torch.cat([off // 128, (off + labels_of_cell.to(torch.int64) * 4) // 128])).numel()
+    return lines * 128.0 + 8.0 * row_index.numel()
+
+
 def run():
     import torch
     import warp_rnnt
@@ -62,7 +72,12 @@ def run():
         for ragged in (False, True):
             xn, yn = (t.to(dev) for t in lengths(torch, N, T, U, ragged, T + U))
             cells = int((xn.long() * (yn.long() + 1)).sum().item())
-            common = {"N": N, "T": T, "U": U, "V": V, "ragged": ragged, "live_cells": cells, "padded_cells": N * T * U}
+            lab = torch.zeros((N, U), dtype=torch.int64, device=dev)
+            lab[:, :U - 1] = ys
+            padded_lines = gather_line_bytes(torch, torch.arange(N * T * U, device=dev),
+                                             lab[:, None, :].expand(N, T, U).reshape(-1), V)
+            common = {"N": N, "T": T, "U": U, "V": V, "ragged": ragged, "live_cells": cells, "padded_cells": N * T * U,
+                      "gather_line_bytes": padded_lines}
 
             def section(path, fn):
                 fn()                                   # warm (allocator, lazy init)
@@ -83,6 +98,9 @@ def run():
                 rows = torch.cat([lp[n, :int(xn[n]), :int(yn[n]) + 1].reshape(-1, V) for n in range(N)]).contiguous()
                 labs = torch.cat([ys[n, :int(yn[n])] for n in range(N)]).contiguous()
                 del lp
+                clab = torch.cat([torch.cat([ys[n, :int(yn[n])].long(), torch.zeros(1, dtype=torch.int64, device=dev)])
+                                  .repeat(int(xn[n])) for n in range(N)])
+                common["gather_line_bytes"] = gather_line_bytes(torch, torch.arange(rows.shape[0], device=dev), clab, V)
                 section("rnnt_loss(compact=True, bounds)",
                         lambda: warp_rnnt.rnnt_loss(rows, labs, xn, yn, compact=True, max_frames=T, max_labels=U - 1))
                 del rows, labs
@@ -146,21 +164,28 @@ def report(trace_csv, manifest_json):
         span = (int(rows[b - 1]["End_Timestamp"]) - int(rows[a]["Start_Timestamp"])) / 1e3 / s["reps"] if b > a else 0.0
         print(f"## N={s['N']} T={s['T']} U={s['U']} V={s['V']} {'ragged' if s['ragged'] else 'full'} -- {s['path']}"
               f"  ({span:.1f} us per call, lattice: {s['lattice']})\n")
-        print("| kernel | launches/call | avg us | algorithmic bytes | GB/s | of 8 TB/s |")
-        print("|---|---|---|---|---|---|")
+        print("| kernel | launches/call | avg us | algorithmic bytes | GB/s | of 8 TB/s | 128-byte lines touched | of 8 TB/s |")
+        print("|---|---|---|---|---|---|---|---|")
         for nm, ds in sorted(ks.items(), key=lambda kv: -sum(kv[1])):
             avg = sum(ds) / len(ds)
             ab, rule = algorithmic_bytes(nm, s)
             if ab:
                 gbs = ab / (avg * 1e-6) / 1e9
-                print(f"| `{nm}` | {len(ds) / s['reps']:.1f} | {avg:.1f} | {ab / 1e6:.1f} MB ({rule}) | {gbs:.0f} | {gbs / HBM_PEAK:.3f} |")
+                frac, lines = gbs / HBM_PEAK, ""
+                if ("k_to_diagonal" in nm or "k_gather_compact" in nm) and s.get("gather_line_bytes"):
+                    lb = s["gather_line_bytes"]
+                    frac = lb / (avg * 1e-6) / 1e9 / HBM_PEAK
+                    lines = f"{lb / 1e6:.1f} MB | {frac:.3f}"
+                else:
+                    lines = " | "
+                print(f"| `{nm}` | {len(ds) / s['reps']:.1f} | {avg:.1f} | {ab / 1e6:.1f} MB ({rule}) | {gbs:.0f} | {gbs / HBM_PEAK:.3f} | {lines} |")
                 if avg > 20 and "k_lattice" not in nm and "prepare" not in nm:
-                    worst.append((gbs / HBM_PEAK, nm, s, avg))
+                    worst.append((frac, nm, s, avg))
             else:
-                print(f"| `{nm}` | {len(ds) / s['reps']:.1f} | {avg:.1f} | | | |")
+                print(f"| `{nm}` | {len(ds) / s['reps']:.1f} | {avg:.1f} | | | | | |")
         print()
     worst.sort(key=lambda w: w[0])
-    print("## Streaming kernels furthest below the HBM roofline (launches longer than 20 us)\n")
+    print("## Streaming kernels furthest below the HBM roofline (launches longer than 20 us; the gathers on their lines)\n")
     print("| fraction | kernel | shape | path | avg us |")
     print("|---|---|---|---|---|")
     for fr, nm, s, avg in worst[:15]:

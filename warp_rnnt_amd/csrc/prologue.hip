@@ -1244,12 +1244,25 @@ __global__ void __launch_bounds__(256)
 k_gather_compact(const float* __restrict__ xs, const int* __restrict__ ys, const int* __restrict__ xn,
                  const int* __restrict__ yn, const int64_t* __restrict__ offs,
                  const int* __restrict__ label_offs, float2* __restrict__ ws2, int64_t* __restrict__ loc,
-                 int V, int blank, int tiles_t, int tiles_u) {
+                 int V, int blank, int tiles_t, int tiles_u, int N, int plain_order) {
     __shared__ float2 tile[TD][TD];
+    // The grid covers the batch maxima, so a ragged batch has tiles that lie outside their utterance and return at once.
+    // Workgroups go to the eight XCDs by blockIdx mod 8: with the tile column as the fastest index (tiles_u = 4 at U = 100)
+    // two XCDs would get nothing but last-column tiles, nearly all of them dead.  The utterance is the fastest index
+    // instead, skewed by the tile so that no XCD keeps the same utterances (N=32, T=500, U=100, V=128, lengths 50-100 %:
+    // whole calls: N=64, T=500, U=100 173 -> 150 us, N=32, T=1000, U=100 194 -> 180, nothing at N=32, T=500, U=100; profiles/r04_compact_gather_order_ab.txt).
     unsigned b = blockIdx.x;
-    const int tu = b % tiles_u; b /= tiles_u;
-    const int tt = b % tiles_t;
-    const int n = b / tiles_t;
+    int n, tt, tu;
+    if (plain_order) {
+        tu = b % tiles_u; b /= tiles_u;
+        tt = b % tiles_t;
+        n = b / tiles_t;
+    } else {
+        const unsigned rest = b / (unsigned)N;
+        n = (int)((b % (unsigned)N + rest) % (unsigned)N);
+        tu = rest % tiles_u;
+        tt = rest / tiles_u;
+    }
     const int T = xn[n], U = yn[n] + 1;
     const int t0 = tt * TD, u0 = tu * TD;
     if (t0 >= T || u0 >= U) return;                    // whole tile outside this utterance (uniform)
@@ -1291,9 +1304,10 @@ hipError_t launch_gather_compact(hipStream_t stream, const float* xs, const int*
     const int tiles_t = (Tmax + TD - 1) / TD, tiles_u = (Umax + TD - 1) / TD;
     const size_t nblk = (size_t)N * tiles_t * tiles_u;
     if (nblk >= ((size_t)1 << 31)) return hipErrorInvalidValue;
+    static const bool plain_order = getenv("RNNT_COMPACT_PLAIN_TILE_ORDER") != nullptr;      // A/B runs
     k_gather_compact<<<(unsigned)nblk, 256, 0, stream>>>(xs, ys, xn, yn, offs, label_offs,
                                                          reinterpret_cast<float2*>(ws2), loc, V, blank,
-                                                         tiles_t, tiles_u);
+                                                         tiles_t, tiles_u, N, plain_order ? 1 : 0);
     return hipGetLastError();
 }
 
