@@ -55,6 +55,26 @@ def test_gather_true_equals_dense_path():
     np.testing.assert_allclose(grads[0][1], ref["grads"], atol=1e-4)
 
 
+@pytest.mark.parametrize("name", ["forward_single", "forward_batch", "one_to_many"])
+def test_reference_golden_through_gather_true_backward(name):
+    """The golden vectors of the reference's dense tests (test.py:34-188; the TensorFlow binding's test_forward_single
+    holds the same numbers, tensorflow_binding/warp_rnnt_tf/test.py) through the WRAPPER's gather=True path:
+    rnnt_loss(log_softmax(logits), gather=True) + backward() must give the golden costs and the golden dense
+    (N,T,U,V) gradients, within the reference's own tolerance."""
+    import warp_rnnt
+    from helpers import reference_cases
+    case = [c for c in reference_cases(("dense",)) if c["name"] == name][0]
+    lp0 = np_log_softmax32(np.array(case["logits"], dtype=np.float32))
+    N, _, U, _ = lp0.shape
+    lp = T(lp0).requires_grad_(True)
+    costs = warp_rnnt.rnnt_loss(lp, T(np.array(case["labels"], dtype=np.int32).reshape(N, U - 1)),
+                                T(np.array(case["xn"], dtype=np.int32)),
+                                T(np.array(case["yn"], dtype=np.int32)), gather=True, blank=case["blank"])
+    np.testing.assert_allclose(costs.detach().cpu().numpy(), np.array(case["costs"]), atol=1.5e-6, rtol=0)
+    costs.sum().backward()
+    np.testing.assert_allclose(lp.grad.cpu().numpy(), np.array(case["grads"]), atol=1.5e-6, rtol=0)
+
+
 def test_forward_computes_grads_without_requires_grad_and_second_backward():
     """Appendix B: grads are produced in forward; backward is a broadcast multiply and can be
     repeated (the reference multiplies in place, which would double-scale)."""

@@ -424,11 +424,17 @@ static thread_local rnntStatus_t g_compact_status = RNNT_STATUS_SUCCESS;
 // failure impossible to miss downstream: costs become NaN (best effort, NULL stream like everything here) instead
 // of whatever torch.empty held, so a training loop that ignores the status stops on a NaN loss rather than
 // learning from uninitialised memory.
-static void compact_fail(rnntStatus_t st, const char* what, float* costs, unsigned int N) {
+// `err` is what the failed launcher returned (it has already taken the error off the runtime's per-thread slot, so
+// asking hipGetLastError() here would report "no error").
+static void compact_fail(rnntStatus_t st, const char* what, float* costs, unsigned int N, hipError_t err = hipSuccess) {
     g_compact_status = st;
     fprintf(stderr, "%s failed: rnnt status %d (%s)\n", what, (int)st,
-            st == RNNT_STATUS_INVALID_ARGUMENT ? "invalid argument or unsupported size" : hipGetErrorString(hipGetLastError()));
-    if (costs && N) (void)hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(costs), 0x7fc00000, N, nullptr);
+            st == RNNT_STATUS_INVALID_ARGUMENT ? "invalid argument or unsupported size" : hipGetErrorString(err));
+    if (costs && N) {
+        const hipError_t m = hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(costs), 0x7fc00000, N, nullptr);
+        if (m != hipSuccess)
+            fprintf(stderr, "%s: costs could not be set to NaN either (%s)\n", what, hipGetErrorString(m));
+    }
 }
 
 rnntStatus_t rnnt_amd_compact_last_status(void) {
@@ -443,9 +449,10 @@ void run_gather_for_compact(const float* xs, const int* ys, const unsigned int* 
                             unsigned int V, unsigned int blank) {
     static_assert(sizeof(long) == sizeof(int64_t), "loc is the reference's `long` (at::kLong)");
     if (V < 1 || blank >= V) { compact_fail(RNNT_STATUS_INVALID_ARGUMENT, "run_gather_for_compact", nullptr, 0); return; }
-    if (launch_gather_compact_rowmajor(nullptr, xs, ys, xn, yn, gather_xs, reinterpret_cast<int64_t*>(loc), memPref,
-                                       labelPref, N, T, U, V, blank) != hipSuccess)
-        compact_fail(RNNT_STATUS_PROLOGUE_FAILED, "run_gather_for_compact", nullptr, 0);
+    const hipError_t e = launch_gather_compact_rowmajor(nullptr, xs, ys, xn, yn, gather_xs,
+                                                        reinterpret_cast<int64_t*>(loc), memPref, labelPref, N, T, U, V,
+                                                        blank);
+    if (e != hipSuccess) compact_fail(RNNT_STATUS_PROLOGUE_FAILED, "run_gather_for_compact", nullptr, 0, e);
 }
 
 void run_warp_rnnt_compact(unsigned int* counts, float* alphas, float* betas, const float* log_probs, float* grads,
@@ -465,29 +472,30 @@ void run_warp_rnnt_compact(unsigned int* counts, float* alphas, float* betas, co
     LatticeArgs la{log_probs, nullptr, ixn, iyn, alphas, betas, ll, (int)T, (int)U, 2, 0};
     la.offs32 = memPref;
     la.beta_only = required_grad ? 0 : 1;
-    if (launch_lattice(nullptr, la, (int)N, LOAD_ROWMAJOR2) != hipSuccess) {
-        compact_fail(RNNT_STATUS_WARP_FAILED, "run_warp_rnnt_compact", costs, N);
+    hipError_t e = launch_lattice(nullptr, la, (int)N, LOAD_ROWMAJOR2);
+    if (e != hipSuccess) {
+        compact_fail(RNNT_STATUS_WARP_FAILED, "run_warp_rnnt_compact", costs, N, e);
         return;
     }
     if (!required_grad) {   // the reference's "beta only" inference mode: costs from beta[0,0], nothing else is touched
-        if (launch_costs_from_betas(nullptr, betas, memPref, ixn, iyn, costs, (int)N) != hipSuccess)
-            compact_fail(RNNT_STATUS_COSTS_FAILED, "run_warp_rnnt_compact", costs, N);
+        e = launch_costs_from_betas(nullptr, betas, memPref, ixn, iyn, costs, (int)N);
+        if (e != hipSuccess) compact_fail(RNNT_STATUS_COSTS_FAILED, "run_warp_rnnt_compact", costs, N, e);
         return;
     }
     GradArgs ga{log_probs, nullptr, ixn, iyn, alphas, betas, ll, grads, costs, nullptr, (int)T, (int)U, 2, 0,
                 fastemit_lambda};
     ga.offs32 = memPref;
-    if (launch_grads(nullptr, ga, (int)N, LOAD_ROWMAJOR2, WRITE_ROWMAJOR2) != hipSuccess)
-        compact_fail(RNNT_STATUS_GRADS_BLANK_FAILED, "run_warp_rnnt_compact", costs, N);
+    e = launch_grads(nullptr, ga, (int)N, LOAD_ROWMAJOR2, WRITE_ROWMAJOR2);
+    if (e != hipSuccess) compact_fail(RNNT_STATUS_GRADS_BLANK_FAILED, "run_warp_rnnt_compact", costs, N, e);
 }
 
 void run_scatter_grad_for_compact(const float* grad_cost, const float* gather_grad, const long* loc,
                                   const int* cum_lens, float* scatter_grad, unsigned int STU, unsigned int N,
                                   unsigned int V, unsigned int blank) {
     if (V < 1 || blank >= V) { compact_fail(RNNT_STATUS_INVALID_ARGUMENT, "run_scatter_grad_for_compact", nullptr, 0); return; }
-    if (launch_scatter_compact(nullptr, grad_cost, gather_grad, reinterpret_cast<const int64_t*>(loc), cum_lens,
-                               scatter_grad, (int64_t)STU, (int)N, (int)V, (int)blank) != hipSuccess)
-        compact_fail(RNNT_STATUS_EXPAND_FAILED, "run_scatter_grad_for_compact", nullptr, 0);
+    const hipError_t e = launch_scatter_compact(nullptr, grad_cost, gather_grad, reinterpret_cast<const int64_t*>(loc),
+                                                cum_lens, scatter_grad, (int64_t)STU, (int)N, (int)V, (int)blank);
+    if (e != hipSuccess) compact_fail(RNNT_STATUS_EXPAND_FAILED, "run_scatter_grad_for_compact", nullptr, 0, e);
 }
 
 rnntStatus_t rnnt_amd_expand_grads(rnntStream_t stream, const float* grads_diagonal, const int* labels,
