@@ -43,7 +43,9 @@ def _run(lp2, xn, yn, kernel, lam=0.0):
 # block is wide; batches that put several workgroups on every CU
 SHAPES = [(3, 37, 70, True), (2, 5, 130, False), (4, 200, 65, True), (2, 150, 64, False), (16, 150, 40, False),
           (5, 333, 129, True), (4, 600, 300, True), (2, 64, 512, False), (70, 90, 200, True), (3, 1, 100, True),
-          (2, 700, 257, False), (300, 40, 130, True)]
+          (2, 700, 257, False), (300, 40, 130, True),
+          # one column block per sweep: the plain launch (no rings, no queue, no redo kernel behind)
+          (300, 40, 33, True), (3, 5, 20, True), (2, 1, 30, False), (130, 200, 64, True), (3, 100, 1, False)]
 
 
 @pytest.mark.parametrize("N,T,U,ragged", SHAPES)
@@ -162,10 +164,10 @@ print("WD_SHORT_SPIN_OK", bad)
     assert out.returncode == 0 and "WD_SHORT_SPIN_OK" in text, text[-4000:]
 
 
-def test_compact_layout_same_bits():
+@pytest.mark.parametrize("N,T,U,V", [(5, 220, 150, 7), (6, 120, 50, 7)])      # (the second: one column block, plain launch)
+def test_compact_layout_same_bits(N, T, U, V):
     """The native compact entry (64-bit cell offsets): per-utterance planes, rings sized by the launch bounds."""
     import warp_rnnt
-    N, T, U, V = 5, 220, 150, 7
     logits, labels, xn, yn = make_case(9, N, T, U, V, ragged=True)
     lp = torch.tensor(np_log_softmax32(logits), device=DEV)
     tl, txn, tyn = (torch.tensor(a, device=DEV) for a in (labels, xn, yn))

@@ -580,6 +580,18 @@ hipError_t launch_lattice(hipStream_t stream, const LatticeArgs& a, int N, int l
         if (nA > ws::MAXA_HOST) use_wd = ring_ok;             // wider than one workgroup sweeps: column blocks or stripes
         if (kern == 1) use_wd = false;
         if (kern == 2) use_wd = ring_ok;
+        // One column block per sweep (U <= 64): nothing is handed over, so the distributed kernel needs neither the ring
+        // preparation in front nor the redo kernel behind -- a plain launch of its three-wave workgroups (LDS-DMA loader,
+        // store-only storer, warm instruction cache), faster than lattice_ws.hip's compute + I/O wave pair at every size
+        // (us, ws / wd: N=16, T=150, U=40 16.1 / 15.0; N=32, T=150, U=20 15.1 / 13.7; N=256, T=150, U=40 19.4 / 16.6;
+        // N=32, U=50: T=250 22.5 / 21.0, T=500 36.8 / 33.6, T=1000 64.8 / 58.6; N=256, T=500 42.7 / 34.5; T=1500, U=64
+        // 93 / 84; profiles/r04_lattice_routes_single_block.txt).  RNNT_WD_LONE_FROM_T=<T>: only from that T on (A/B).
+        static const int wd_lone_t = getenv("RNNT_WD_LONE_FROM_T") ? atoi(getenv("RNNT_WD_LONE_FROM_T")) : 0;
+        if (nA == 1 && !a.offs32 && kern != 1 && (kern == 2 || a.T >= wd_lone_t)) {
+            const hipError_t e = launch_lattice_wd(stream, plain, N);
+            g_last_kernel = 2;
+            if (e != hipErrorNotSupported) return e;
+        }
         if (use_wd) {
             const hipError_t e = launch_lattice_wd(stream, a, N);
             g_last_kernel = 2;

@@ -422,8 +422,10 @@ __global__ void __launch_bounds__(3 * WAVE) k_lattice_wd(LatticeArgs a, const in
     __shared__ int wg_bad, s_item;
     // launch epoch = host counter (constant across the replays of a captured graph) + the library's per-device launch
     // counter (queue[1], bumped by the preparation kernel in front of every launch, replayed or not)
-    a.epoch += (unsigned)a.queue[1];
-    if (threadIdx.x == 0) { s_item = atomicAdd(a.queue, 1); wg_bad = 0; }
+    // (a.queue == nullptr: the launch of single-column-block lattices -- nothing is handed over, so there is no work
+    //  queue, no ring, no tag and nothing that could flag a sweep: items in launch order)
+    if (a.queue) a.epoch += (unsigned)a.queue[1];
+    if (threadIdx.x == 0) { s_item = a.queue ? atomicAdd(a.queue, 1) : (int)blockIdx.x; wg_bad = 0; }
     __syncthreads();
     const int sweeps = gridDim.x / nA;                 // 2N
     Item it;
@@ -445,7 +447,7 @@ __global__ void __launch_bounds__(3 * WAVE) k_lattice_wd(LatticeArgs a, const in
 #undef RNNT_WD_SWEEP
     }
     __syncthreads();
-    if (threadIdx.x == 0 && wg_bad) atomicOr(&a.redo[2 * it.n + it.dir], wg_bad);
+    if (threadIdx.x == 0 && wg_bad && a.redo) atomicOr(&a.redo[2 * it.n + it.dir], wg_bad);
 }
 
 }  // namespace wd
@@ -460,21 +462,31 @@ size_t wd_mail_bytes(int N, int T, int U) {
 }
 
 // Needs a.redo, a.queue = a.redo + 2N with the launch counter behind it (and a.mail of wd_mail_bytes when U > 64);
-// zeroes redo, the queue head and the rings itself.  Sweeps it flags in a.redo (a lost hand-over: never observed
+// zeroes redo, the queue head and the rings itself.  With a.redo == nullptr and U <= 64 it is a plain launch.  Sweeps it flags in a.redo (a lost hand-over: never observed
 // outside the short-spin build) are for the caller to redo with the single-workgroup kernel.
 hipError_t launch_lattice_wd(hipStream_t stream, const LatticeArgs& a0, int N) {
     if (N <= 0) return hipSuccess;
     const int nA = (a0.U + WAVE - 1) / WAVE;
-    if (!a0.redo || !a0.queue || (nA > 1 && !a0.mail) || a0.offs32) return hipErrorNotSupported;
+    if (a0.offs32) return hipErrorNotSupported;
 #ifdef RNNT_WD_STATS
-    if (!a0.mail) return hipErrorNotSupported;
+    if (!a0.mail || !a0.redo || !a0.queue) return hipErrorNotSupported;
+    const bool lone = false;
+#else
+    // one column block per sweep (U <= 64) and no flags asked for: nothing to prepare, nothing to redo behind
+    const bool lone = nA == 1 && !a0.redo;
 #endif
+    if (!lone && (!a0.redo || !a0.queue || (nA > 1 && !a0.mail))) return hipErrorNotSupported;
     if ((long long)2 * N * nA >= (1ll << 31)) return hipErrorNotSupported;
     LatticeArgs a = a0;
-    a.epoch = next_launch_epoch();
-    const size_t ring_bytes = nA < 2 ? 0 : (size_t)2 * N * (nA - 1) * wd::ring_pitch(a.T, a.U) * sizeof(wd::u64);
-    hipError_t e = launch_ring_prepare(stream, a.redo, 2 * N + 1, a.mail, ring_bytes);
-    if (e != hipSuccess) return e;
+    if (lone) {
+        a.queue = nullptr;
+        a.mail = nullptr;
+    } else {
+        a.epoch = next_launch_epoch();
+        const size_t ring_bytes = nA < 2 ? 0 : (size_t)2 * N * (nA - 1) * wd::ring_pitch(a.T, a.U) * sizeof(wd::u64);
+        const hipError_t e = launch_ring_prepare(stream, a.redo, 2 * N + 1, a.mail, ring_bytes);
+        if (e != hipSuccess) return e;
+    }
     const dim3 grid(2 * N * nA), block(3 * WAVE);
     if (a.offs)
         wd::k_lattice_wd<true><<<grid, block, 0, stream>>>(a, nA);
