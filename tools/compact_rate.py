@@ -52,7 +52,13 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "--child":
         child()
     else:
-        settings = [{}] + [dict([a.split("=", 1)]) for a in sys.argv[1:]]
+        # NAME=VALUE: environment variables; lib:<name>=<path>: another build of the library
+        settings = [{}]
+        for a in sys.argv[1:]:
+            if a.startswith("lib:"):
+                settings.append({"WARP_RNNT_AMD_LIB": os.path.abspath(a[4:].split("=", 1)[1]), "WARP_RNNT_AMD_NO_NATIVE_BINDING": "1"})
+            else:
+                settings.append(dict([a.split("=", 1)]))
         for env in settings:
             print("== " + (" ".join(f"{k}={v}" for k, v in env.items()) or "shipped"), flush=True)
             subprocess.run([sys.executable, os.path.abspath(__file__), "--child"], env=dict(os.environ, **env), check=True)

@@ -337,7 +337,7 @@ rnntStatus_t rnnt_amd_loss_compact(rnntStream_t stream, void* workspace, const f
     float *alphas = w.alphas, *betas = w.betas, *ws2 = w.ws2, *ll = w.ll;
     int* mismatch = w.mismatch;
     if (launch_gather_compact(stream, xs, ys, xn, yn, cell_offsets, label_offsets, ws2, loc, N, Tmax, Umax, V,
-                              blank) != hipSuccess)
+                              blank, STU) != hipSuccess)
         return RNNT_STATUS_PROLOGUE_FAILED;
     LatticeArgs la{ws2, nullptr, xn, yn, alphas, betas, ll, Tmax, Umax, 2, 0, cell_offsets, w.redo, w.redo + 2 * N, w.mail};
     la.route = lattice_route();

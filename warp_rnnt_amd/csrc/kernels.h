@@ -128,7 +128,7 @@ hipError_t launch_compact_offsets(hipStream_t stream, const int* xn, const int* 
 hipError_t launch_zero_if_refused(hipStream_t stream, const int64_t* refused, float* grads2, size_t cells);
 hipError_t launch_gather_compact(hipStream_t stream, const float* xs, const int* ys, const int* xn,
                                  const int* yn, const int64_t* offs, const int* label_offs, float* ws2,
-                                 int64_t* loc, int N, int Tmax, int Umax, int V, int blank);
+                                 int64_t* loc, int N, int Tmax, int Umax, int V, int blank, int64_t STU);
 hipError_t launch_scatter_compact(hipStream_t stream, const float* grad_cost, const float* grads2,
                                   const int64_t* loc, const int* cum_lens, float* out, int64_t STU, int N,
                                   int V, int blank);

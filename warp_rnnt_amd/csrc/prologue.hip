@@ -1297,10 +1297,86 @@ k_gather_compact(const float* __restrict__ xs, const int* __restrict__ ys, const
     }
 }
 
+// The same gather over the LIVE cells in their packed order: workgroup b takes cells [1024 b, 1024 b + 1024) of the
+// (STU, V) tensor whatever utterances they belong to -- no tile outside its utterance, no partly filled tile, every
+// workgroup the same amount of work (the tiled kernel above reaches 0.44-0.53 of the line rate on ragged batches of
+// 0.1-0.4 GB because its grid covers the batch maxima: profiles/r04_shape_map.md).  Every lane reads its two dwords from
+// a row of its own either way, so nothing is lost on the read side; the pairs leave as scattered 8-byte stores (the
+// tiles write runs of up to 256 bytes), loc as one coalesced stream.
+#ifndef RNNT_GCL_CELLS
+#define RNNT_GCL_CELLS 4
+#endif
+constexpr int GCL_CELLS = RNNT_GCL_CELLS;       // cells per thread
+__global__ void __launch_bounds__(256)
+k_gather_compact_linear(const float* __restrict__ xs, const int* __restrict__ ys, const int* __restrict__ xn,
+                        const int* __restrict__ yn, const int64_t* __restrict__ offs,
+                        const int* __restrict__ label_offs, float2* __restrict__ ws2, int64_t* __restrict__ loc,
+                        int V, int blank, int N, int64_t STU) {
+    __shared__ int s_n0;
+    const int tid = threadIdx.x;
+    const int64_t c0 = (int64_t)blockIdx.x * (256 * GCL_CELLS);
+    if (tid == 0) s_n0 = N;
+    __syncthreads();
+    // the utterance the chunk starts in (utterances without cells never match; a refused batch -- every checked length 0
+    // -- is dropped below)
+    for (int n = tid; n < N; n += 256)
+        if (offs[n] <= c0 && c0 < offs[n + 1]) s_n0 = n;
+    __syncthreads();
+    const int n0 = s_n0;
+    if (n0 >= N) return;
+    float2 pair[GCL_CELLS];
+    size_t dst[GCL_CELLS];
+    int labs[GCL_CELLS];
+    bool live[GCL_CELLS];
+#pragma unroll
+    for (int k = 0; k < GCL_CELLS; ++k) {
+        const int64_t c = c0 + tid + 256 * k;
+        live[k] = false;
+        pair[k] = make_float2(0.0f, 0.0f);
+        dst[k] = 0;
+        labs[k] = blank;
+        if (c >= STU) continue;
+        int n = n0;
+        while (n < N && c >= offs[n + 1]) ++n;
+        if (n >= N) continue;
+        const int T = xn[n], U = yn[n] + 1;
+        if (T < 1 || U < 1) continue;
+        const unsigned local = (unsigned)(c - offs[n]);
+        const unsigned t = local / (unsigned)U;
+        const int u = (int)(local - t * (unsigned)U);
+        if ((int)t >= T) continue;
+        if (u < U - 1) labs[k] = safe_label(ys[label_offs[n] + u], V, blank);
+        const float* p = xs + (size_t)c * (size_t)V;
+        pair[k] = make_float2(__builtin_nontemporal_load(p + blank), __builtin_nontemporal_load(p + labs[k]));
+        int r = (int)t + u;
+        r = r >= T ? r % T : r;
+        dst[k] = (size_t)offs[n] + (size_t)r * U + u;
+        live[k] = true;
+    }
+#pragma unroll
+    for (int k = 0; k < GCL_CELLS; ++k) {
+        if (!live[k]) continue;
+        ws2[dst[k]] = pair[k];
+        if (loc) loc[c0 + tid + 256 * k] = labs[k];
+    }
+}
+
 hipError_t launch_gather_compact(hipStream_t stream, const float* xs, const int* ys, const int* xn,
                                  const int* yn, const int64_t* offs, const int* label_offs, float* ws2,
-                                 int64_t* loc, int N, int Tmax, int Umax, int V, int blank) {
+                                 int64_t* loc, int N, int Tmax, int Umax, int V, int blank, int64_t STU) {
     if (N <= 0 || Tmax <= 0 || Umax <= 0) return hipSuccess;
+    // RNNT_COMPACT_GATHER=tiles|linear pins one of the two kernels (A/B runs)
+    static const char* pin = getenv("RNNT_COMPACT_GATHER");
+    const bool want_linear = pin ? pin[0] == 'l' : true;
+    if (want_linear && STU > 0 && N <= 4096) {
+        const int64_t nblk = (STU + 256 * GCL_CELLS - 1) / (256 * GCL_CELLS);
+        if (nblk < ((int64_t)1 << 31)) {
+            k_gather_compact_linear<<<(unsigned)nblk, 256, 0, stream>>>(xs, ys, xn, yn, offs, label_offs,
+                                                                        reinterpret_cast<float2*>(ws2), loc, V, blank,
+                                                                        N, STU);
+            return hipGetLastError();
+        }
+    }
     const int tiles_t = (Tmax + TD - 1) / TD, tiles_u = (Umax + TD - 1) / TD;
     const size_t nblk = (size_t)N * tiles_t * tiles_u;
     if (nblk >= ((size_t)1 << 31)) return hipErrorInvalidValue;
