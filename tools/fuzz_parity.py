@@ -26,7 +26,7 @@ BIG_FRACTION = 0.0
 
 
 def draw_case(rng):
-    kind = rng.randint(10)
+    kind = rng.randint(12)
     if rng.rand() < BIG_FRACTION:   # BASELINE-size lattices (five column blocks, ~1800 diagonals), ragged
         N, T, U, V = rng.randint(1, 4), rng.randint(900, 1501), rng.randint(200, 301), rng.randint(2, 12)
     elif kind < 5:
@@ -37,8 +37,11 @@ def draw_case(rng):
         N, T, U, V = rng.randint(1, 3), rng.randint(1, 40), rng.randint(1000, 1100), 3
     elif kind < 9:      # large vocabulary kernels (row per workgroup / generic)
         N, T, U, V = rng.randint(1, 4), rng.randint(1, 30), rng.randint(1, 12), int(rng.choice([1024, 1025, 4096, 5000, 17000]))
-    else:               # many utterances
+    elif kind < 10:     # many utterances
         N, T, U, V = rng.randint(40, 200), rng.randint(1, 30), rng.randint(1, 20), rng.randint(2, 12)
+    else:               # mid vocabularies: the rows-in-registers fused gather (whole-line rows; any V % 4 == 0 above 256)
+        N, T, U = rng.randint(1, 5), rng.randint(1, 60), rng.randint(1, 40)
+        V = int(rng.choice([32, 64, 96, 128, 160, 192, 224, 256, 260, 320, 400, 500, 512, 600, 768, 1000, 1024]))
     if U == 1:
         V = max(V, 2)
     blank = int(rng.randint(V)) if rng.rand() < 0.5 else 0
