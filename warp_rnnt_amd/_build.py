@@ -13,7 +13,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libwarp_rnnt_amd.so")
 SOURCES = ["api.hip", "lattice.hip", "lattice_ws.hip", "lattice_wd.hip", "lattice_pd.hip", "grads.hip", "prologue.hip",
            "expand.hip"]
-HEADERS = ["common.h", "kernels.h", "lattice_step.h", os.path.join("..", "..", "include", "warp_rnnt_amd.h")]
+HEADERS = ["common.h", "kernels.h", "lattice_step.h", "grads_cell.h", os.path.join("..", "..", "include", "warp_rnnt_amd.h")]
 ARCH = "gfx950"
 
 

@@ -3,6 +3,7 @@
 #include "../../include/warp_rnnt_amd.h"
 
 #include <cstdio>
+#include <cstdlib>
 
 #include "common.h"
 #include "kernels.h"
@@ -17,6 +18,17 @@ constexpr size_t ALIGN = 256;
 // U=40: 24 us in two launches against 35 in five; N=16, T=1500, U=300: 500 against 274)
 constexpr size_t STAGED_FROM_CELLS = (size_t)1 << 20;
 inline size_t align_up(size_t x) { return (x + ALIGN - 1) / ALIGN * ALIGN; }
+// Dense gradients: up to this many lattice cells the gradient kernel and the expansion run as ONE launch whose row writer
+// reads alpha / beta / pairs itself (scattered reads of planes that sit in L2 / the Infinity Cache); above, two streaming
+// launches.  One launch / two (tools/dense_rate.py, profiles/r04_grads_dense_ab.txt; us per call of the dense entry):
+// T=150, U=40, V=28: N=16 28.2 / 30.7, N=32 35.0 / 37.6, N=64 46.2 / 48.2, N=128 67.0 / 68.7, N=256 114 / 113;
+// T=500, U=100, V=50: N=4 ... 32 (0.2 M ... 1.6 M cells) equal within 0.5 us.  RNNT_DENSE_ONE_LAUNCH_CELLS overrides
+// (0: never), for A/B runs.
+inline size_t dense_in_one_launch_cells() {
+    static const size_t v = getenv("RNNT_DENSE_ONE_LAUNCH_CELLS") ? (size_t)atoll(getenv("RNNT_DENSE_ONE_LAUNCH_CELLS"))
+                                                                  : ((size_t)1 << 20);
+    return v;
+}
 
 struct Workspace {
     float* alphas;
@@ -236,6 +248,14 @@ rnntStatus_t rnnt_amd_loss(rnntStream_t stream, void* workspace, int input_kind,
     const bool unskew_gathered = grads_kind == RNNT_GRADS_GATHERED && (size_t)N * T * U >= STAGED_FROM_CELLS;
     if (grads_kind == RNNT_GRADS_GATHERED && !unskew_gathered) writer = WRITE_ROWMAJOR2;   // (launch-bound sizes: direct)
     else if (grads_kind != RNNT_GRADS_GATHERED_DIAGONAL) gout = w.ws2;
+    if (grads_kind == RNNT_GRADS_DENSE && (size_t)N * T * U <= dense_in_one_launch_cells()) {
+        // launch-bound sizes: the gradient kernel and the expansion as one launch (c2 in bench.py: 0.0371 -> 0.0348 ms per
+        // step); the row writer reads its cells' values from the planes itself
+        GradArgs gd{w.ws2, labels, xn, yn, w.alphas, w.betas, w.ll, nullptr, costs, w.mismatch, T, U, V, blank,
+                    fastemit_lambda};
+        if (launch_grads_dense(stream, gd, grads, N) != hipSuccess) return RNNT_STATUS_GRADS_BLANK_FAILED;
+        return RNNT_STATUS_SUCCESS;
+    }
     GradArgs ga{w.ws2, nullptr, xn, yn, w.alphas, w.betas, w.ll, gout, costs, w.mismatch,
                 T, U, 2, 0, fastemit_lambda};
     if (launch_grads(stream, ga, N, LOAD_SKEWED, writer) != hipSuccess)

@@ -20,6 +20,7 @@
 // cell's two slots.  (The first version -- one thread per float4 with its own
 // index divisions -- was VALU-bound at 2.4 TB/s.)
 #include "common.h"
+#include "grads_cell.h"
 #include "kernels.h"
 
 namespace rnnt {
@@ -95,6 +96,48 @@ struct SplitRows {     // as PaddedRows, the two channels in two float planes (t
         ExpandCell c;
         c.gB = ga[at];
         c.gL = gb[at];
+        c.lab = (u < U - 1) ? labels[(size_t)n * (U - 1) + u] : blank;
+        if ((unsigned)c.lab >= (unsigned)V) c.lab = -1;
+        // dense-kernel rule (core.cu:382-393), as PaddedRows in overwrite mode
+        const bool labvalid = (t < xn[n]) && (u < yn[n]);
+        if (!labvalid) c.lab = -1;
+        else if (c.lab == blank) c.gB = c.gL;
+        if (labvalid && c.lab == blank) c.lab = -1;
+        return c;
+    }
+};
+struct GradRows {      // the dense forward result computed straight from the planes: k_grads and the expansion in one launch
+    // (small lattices, whose planes sit in L2: the cell's seven dwords are scattered reads here, one lane per row)
+    const float2* lp2; const float* alphas; const float* betas; const float* ll;
+    const int* labels; const int* xn; const int* yn; float* costs; int* mismatch;
+    int T, U, V, blank; float fastemit_lambda;
+    __device__ __forceinline__ ExpandCell operator()(unsigned cell) const {
+        const unsigned frame = cell / (unsigned)U;
+        const int u = (int)(cell - frame * (unsigned)U);
+        const unsigned n = frame / (unsigned)T;
+        const int t = (int)(frame - n * (unsigned)T);
+        const UttLens len = utt_lens<false>(xn, yn, (int)n, T, U);
+        const size_t nb = (size_t)n * T * U;
+        const float* __restrict__ be = betas + nb;
+        const UttGuard guard = utt_guard(be[0], ll[n], len.ok);
+        if (t == 0 && u == 0) {
+            costs[n] = utt_cost(guard, len.ok);
+            if (mismatch) mismatch[n] = guard.bad ? 1 : 0;
+        }
+        int r = t + u;
+        r = r >= T ? r % T : r;
+        ExpandCell c;
+        c.gB = 0.0f;
+        c.gL = 0.0f;
+        if (t < len.Tn && u < len.Un && !guard.bad) {
+            const size_t idx = (size_t)r * U + u;
+            const float2 v = lp2[nb + idx];
+            const int r1 = (r + 1 == T) ? 0 : r + 1;
+            const float2 g = cell_grads(alphas[nb + idx], v.x, v.y, guard.b00, t, u, len.Tn, len.Un, fastemit_lambda,
+                                        [&](int col) { return be[(size_t)r1 * U + col]; });
+            c.gB = g.x;
+            c.gL = g.y;
+        }
         c.lab = (u < U - 1) ? labels[(size_t)n * (U - 1) + u] : blank;
         if ((unsigned)c.lab >= (unsigned)V) c.lab = -1;
         // dense-kernel rule (core.cu:382-393), as PaddedRows in overwrite mode
@@ -202,6 +245,15 @@ hipError_t launch_expand(hipStream_t stream, const float* g2_skewed, const int* 
     const PaddedRows rows{reinterpret_cast<const float2*>(g2_skewed), labels, xn, yn, scale, T, U, V, blank,
                           overwrite_mode};
     return launch_rows(stream, rows, dense, (unsigned)cells64, V, blank);
+}
+
+hipError_t launch_grads_dense(hipStream_t stream, const GradArgs& a, float* dense, int N) {
+    const size_t cells64 = (size_t)N * a.T * a.U;
+    if (cells64 == 0 || a.V == 0) return hipSuccess;
+    if (is_compact(a)) return hipErrorNotSupported;
+    const GradRows rows{reinterpret_cast<const float2*>(a.lp), a.alphas, a.betas, a.ll, a.labels, a.xn, a.yn, a.costs,
+                        a.mismatch, a.T, a.U, a.V, a.blank, a.fastemit_lambda};
+    return launch_rows(stream, rows, dense, (unsigned)cells64, a.V, a.blank);
 }
 
 hipError_t launch_expand_split(hipStream_t stream, const float* ga_skewed, const float* gb_skewed, const int* labels,

@@ -14,6 +14,7 @@
 // beta[t+1,u], beta[t,u+1] (= next diagonal, columns u and u+1) and the
 // workspace log-probs are all coalesced row reads.
 #include "common.h"
+#include "grads_cell.h"
 #include "kernels.h"
 
 namespace rnnt {
@@ -39,12 +40,11 @@ __global__ void __launch_bounds__(256) k_grads(const GradArgs a) {
     const bool in = idx < (unsigned)(T * U);
 
     // ---- per-utterance scalars: beta[0,0], alpha-side log-likelihood, guard ----
-    const float b00 = be[0];   // sk(0,0) = 0
-    const float ll_a = a.ll[n];   // alpha[T-1,U-1] + lpB[T-1,U-1], written by the alpha sweep
-    const float ratio = fabsf(ll_a - b00) / fabsf(fmaxf(ll_a, b00));
-    const bool bad = ratio > 0.001f || !len.ok;
+    const UttGuard guard = utt_guard(be[0], a.ll[n], len.ok);   // be[0]: sk(0,0) = 0
+    const float b00 = guard.b00;
+    const bool bad = guard.bad;
     if (idx == 0) {
-        a.costs[n] = !len.ok ? __builtin_nanf("") : bad ? -((ll_a + b00) / 2.0f) : -b00;
+        a.costs[n] = utt_cost(guard, len.ok);
         if (a.mismatch) a.mismatch[n] = bad ? 1 : 0;
     }
     if (!in) return;
@@ -71,17 +71,10 @@ __global__ void __launch_bounds__(256) k_grads(const GradArgs a) {
         }
         const float alpha = al[idx];
         const int r1 = (r + 1 == T) ? 0 : r + 1;
-        if (t < Tn - 1) {
-            const float x = alpha + be[(size_t)r1 * U + u];
-            gB = -expf(x + lpB - b00);
-        } else if (u == Un - 1) {
-            gB = -expf(alpha + lpB - b00);
-        }
-        if (u < Un - 1) {
-            const float x = alpha + be[(size_t)r1 * U + u + 1];
-            const float e = expf(x + lpL - b00);
-            gL = -(float)((1. + a.fastemit_lambda) * e);
-        }
+        const float2 g = cell_grads(alpha, lpB, lpL, b00, t, u, Tn, Un, a.fastemit_lambda,
+                                    [&](int c) { return be[(size_t)r1 * U + c]; });
+        gB = g.x;
+        gL = g.y;
     }
 
     if constexpr (WRITER == WRITE_SKEWED2) {

@@ -64,6 +64,9 @@ struct GradArgs {
 __host__ __device__ inline bool is_compact(const GradArgs& a) { return a.offs || a.offs32; }
 __device__ inline size_t compact_base(const GradArgs& a, int n) { return a.offs ? (size_t)a.offs[n] : (size_t)a.offs32[n]; }
 
+// gradients + costs + guard AND the dense (N,T,U,V) rows in one launch (a.lp = diagonal-major pairs, a.labels, a.V and
+// a.blank of the dense tensor; a.grads unused): for lattices whose planes sit in L2
+hipError_t launch_grads_dense(hipStream_t stream, const GradArgs& a, float* dense, int N);
 hipError_t launch_lattice(hipStream_t stream, const LatticeArgs& a, int N, int loader);
 // wave-specialised log-domain variant (diagonal-major loader only); hipErrorNotSupported when U > 512.
 // With a.redo set only the (utterance, direction) pairs flagged there are swept.
