@@ -61,6 +61,7 @@ fi
 tools/ubench/pd_steps > $OUT/ubench_pd_steps.txt 2>&1
 python tools/host_overhead.py 2>&1 | grep -v amdgpu > $OUT/host_overhead.txt
 (echo "== ctypes fallback"; WARP_RNNT_AMD_NO_NATIVE_BINDING=1 python tools/host_overhead.py 2>&1 | grep -v amdgpu) >> $OUT/host_overhead.txt
+python tools/compact_host_probe.py 2>&1 | grep -v amdgpu > $OUT/compact_host_probe.txt
 python $R/bench.py --no-cpu-baseline --rccl-group > $OUT/bench_c4_rccl_group.json 2>> $OUT/bench.err
 for l in warp-rnnt warp-rnnt-gather warp-rnnt-fused warp-rnnt-compact; do
   timeout 200 python $R/tools/benchmark_table.py --loss $l --markdown $OUT/table_$l.md > $OUT/table_$l.log 2>&1

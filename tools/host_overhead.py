@@ -23,8 +23,5 @@ bench("rnnt_loss(gather=False)", lambda: warp_rnnt.rnnt_loss(lp, ys, xn, yn))
 bench("rnnt_loss(gather=True)", lambda: warp_rnnt.rnnt_loss(lp, ys, xn, yn, gather=True))
 bench("torch.empty_like x3", lambda: (torch.empty_like(lp), torch.empty(16, device='cuda'), torch.empty(100, device='cuda')))
 bench("check_inputs", lambda: core.check_inputs(lp, ys, xn, yn))
-# compact layout: the path with its one read-back (the reference's binding has four), and with caller-supplied bounds
-xs = lp.reshape(-1, V).contiguous(); ysc = ys.reshape(-1).contiguous()
-bench("rnnt_loss(compact=True)  [1 host sync]", lambda: warp_rnnt.rnnt_loss(xs, ysc, xn, yn, compact=True), n=1000)
-bench("rnnt_loss(compact=True, max_frames=, max_labels=)", lambda: warp_rnnt.rnnt_loss(xs, ysc, xn, yn, compact=True,
-                                                                                      max_frames=T, max_labels=U - 1), n=1000)
+# (the compact entry, with launch bounds and with its read-back: tools/compact_host_probe.py -- measured there on its own,
+#  in both orders; as rows of this script they inherit the allocator state the rows above leave behind)
