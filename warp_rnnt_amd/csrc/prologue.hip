@@ -1060,23 +1060,23 @@ constexpr int TD = 32;   // tile edge
 #endif
 constexpr int TT = RNNT_GATHER_TT;   // frames per tile of k_to_diagonal (columns: TD)
 
-template <bool DENSE>
+template <bool DENSE, int TTK>
 __global__ void __launch_bounds__(256)
 k_to_diagonal(const float* __restrict__ src, const int* __restrict__ labels, float2* __restrict__ ws2,
               int T, int U, int V, int blank, int tiles_t, int tiles_u) {
-    __shared__ float2 tile[TT][TD];
+    __shared__ float2 tile[TTK][TD];
     unsigned b = (DENSE && RNNT_GATHER_REVERSE) ? gridDim.x - 1 - blockIdx.x : blockIdx.x;
     const int tu = b % tiles_u; b /= tiles_u;
     const int tt = b % tiles_t;
     const int n = b / tiles_t;
-    const int t0 = tt * TT, u0 = tu * TD;
+    const int t0 = tt * TTK, u0 = tu * TD;
     const int ul = threadIdx.x & (TD - 1), tl0 = threadIdx.x >> 5;   // 8 rows of 32 lanes
     const int u = u0 + ul;
     const size_t nbase = (size_t)n * T * U;
     int lab = blank;
     if (DENSE && u < U - 1) lab = safe_label(labels[(size_t)n * (U - 1) + u], V, blank);
 #pragma unroll
-    for (int k = 0; k < TT / 8; ++k) {
+    for (int k = 0; k < TTK / 8; ++k) {
         const int tl = tl0 + 8 * k, t = t0 + tl;
         if (t < T && u < U) {
             const size_t cell = nbase + (size_t)t * U + u;
@@ -1096,10 +1096,10 @@ k_to_diagonal(const float* __restrict__ src, const int* __restrict__ labels, flo
     // diagonal d of the tile holds cells (tl = d - ul, ul): consecutive ul = consecutive pairs of
     // row (t0+u0+d) mod T of the diagonal-major plane
 #pragma unroll
-    for (int k = 0; k < (TT + TD + 7) / 8; ++k) {
+    for (int k = 0; k < (TTK + TD + 7) / 8; ++k) {
         const int d = tl0 + 8 * k;
         const int tl = d - ul;
-        if (d < TT + TD - 1 && tl >= 0 && tl < TT) {
+        if (d < TTK + TD - 1 && tl >= 0 && tl < TTK) {
             const int t = t0 + tl;
             if (t < T && u < U) {
                 int r = t + u;
@@ -1121,19 +1121,32 @@ k_gather_rowmajor(const float* __restrict__ lp, const int* __restrict__ labels, 
     out2[cell] = make_float2(p[blank], p[m.label]);
 }
 
-static hipError_t launch_to_diagonal(hipStream_t stream, const float* src, const int* labels, float* ws2,
-                                     int N, int T, int U, int V, int blank, bool dense) {
-    if ((size_t)N * T * U == 0) return hipSuccess;
-    const int tiles_t = (T + TT - 1) / TT, tiles_u = (U + TD - 1) / TD;
+template <int TTK>
+static hipError_t launch_to_diagonal_tt(hipStream_t stream, const float* src, const int* labels, float* ws2,
+                                        int N, int T, int U, int V, int blank, bool dense) {
+    const int tiles_t = (T + TTK - 1) / TTK, tiles_u = (U + TD - 1) / TD;
     const size_t nblk = (size_t)N * tiles_t * tiles_u;
     if (nblk >= ((size_t)1 << 31)) return hipErrorInvalidValue;
     if (dense)
-        k_to_diagonal<true><<<(unsigned)nblk, 256, 0, stream>>>(src, labels, reinterpret_cast<float2*>(ws2), T, U,
-                                                                V, blank, tiles_t, tiles_u);
+        k_to_diagonal<true, TTK><<<(unsigned)nblk, 256, 0, stream>>>(src, labels, reinterpret_cast<float2*>(ws2), T, U,
+                                                                     V, blank, tiles_t, tiles_u);
     else
-        k_to_diagonal<false><<<(unsigned)nblk, 256, 0, stream>>>(src, labels, reinterpret_cast<float2*>(ws2), T, U,
-                                                                 2, 0, tiles_t, tiles_u);
+        k_to_diagonal<false, TTK><<<(unsigned)nblk, 256, 0, stream>>>(src, labels, reinterpret_cast<float2*>(ws2), T, U,
+                                                                      2, 0, tiles_t, tiles_u);
     return hipGetLastError();
+}
+
+static hipError_t launch_to_diagonal(hipStream_t stream, const float* src, const int* labels, float* ws2,
+                                     int N, int T, int U, int V, int blank, bool dense) {
+    if ((size_t)N * T * U == 0) return hipSuccess;
+    // Small problems: 32-frame tiles do not even give every CU one workgroup (c2: 94 tiles for 256 CUs); 8-frame tiles --
+    // one cell per thread -- quadruple the workgroups (RNNT_GATHER_SMALL_TILES=0 / 1 forces one or the other, for A/B runs)
+    static const int force = getenv("RNNT_GATHER_SMALL_TILES") ? atoi(getenv("RNNT_GATHER_SMALL_TILES")) : -1;
+    const size_t tiles32 = (size_t)N * ((T + TT - 1) / TT) * ((U + TD - 1) / TD);
+    // (dense entry, us per call, 32- / 8-frame tiles: c2 28.1 / 27.4, N=32 35.1 / 33.2, N=64 46.2 / 45.2, N=128 67.1 / 68.1)
+    const bool small_tiles = force >= 0 ? force != 0 : tiles32 < 512;
+    if (small_tiles) return launch_to_diagonal_tt<8>(stream, src, labels, ws2, N, T, U, V, blank, dense);
+    return launch_to_diagonal_tt<TT>(stream, src, labels, ws2, N, T, U, V, blank, dense);
 }
 
 hipError_t launch_gather(hipStream_t stream, const float* log_probs, const int* labels, float* out2,
