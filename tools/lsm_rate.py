@@ -17,6 +17,7 @@ variants = os.environ.get("LG_VARIANTS", "").split() or [None]
 chunks = os.environ.get("XCD_CHUNKS", "").split() or [None]      # RNNT_XCD_CHUNK values (probe build): XCD run lengths
 cases = [(V, gb, v, c) for V, gb in cases for v in variants for c in chunks]
 backward = bool(os.environ.get("LSM_BACKWARD"))               # time ops.log_softmax_backward (three streams) instead
+inplace = bool(os.environ.get("LSM_INPLACE"))                 # out = x (how c5 runs: 144 GB of logits leave no room for a copy)
 for V, gb, variant, chunk in cases:
     if chunk is not None:
         os.environ["RNNT_XCD_CHUNK"] = chunk
@@ -29,7 +30,7 @@ for V, gb, variant, chunk in cases:
         print(f"[{variant:>8s}] ", end="")
     rows = int(gb * 1e9 / 4 / V)
     x = torch.randn(rows, V, device=dev)
-    out = torch.empty_like(x)
+    out = x if inplace else torch.empty_like(x)
     if backward:
         y = ops.log_softmax(x)
         run = lambda: ops.log_softmax_backward(x, y, grad_in=out)
@@ -49,5 +50,5 @@ for V, gb, variant, chunk in cases:
     ms = statistics.median(ts)
     streams = 3 if backward else 2
     print(f"V={V:6d} rows={rows:9d} in={rows * V * 4 / 1e9:5.2f} GB  {ms * 1e3:8.1f} us  {streams * rows * V * 4 / ms / 1e9:6.2f} TB/s"
-          f"{' (backward: dy, y in, dx out)' if backward else ''}", flush=True)
+          f"{' (backward: dy, y in, dx out)' if backward else ''}{' (in place)' if inplace else ''}", flush=True)
     del x, out
