@@ -113,6 +113,7 @@ enum LsmMode : int {
 struct LsmBwd {
     const float2* g2;    // diagonal-major gathered gradients (RNNT_GRADS_GATHERED_DIAGONAL)
     const float* scale;  // (N,) upstream gradient per utterance, or nullptr
+    int xcd;             // row-per-workgroup kernel: 1 = every XCD streams a contiguous eighth of the rows
 };
 
 #ifndef RNNT_SM_THREADS
@@ -290,7 +291,13 @@ k_lsm_large(const float* x, float* out, const int* __restrict__ labels,
             int64_t rows, int V, int T, int U, int blank, LsmBwd bw) {
     constexpr bool GATHER = MODE == LSM_GATHER;
     __shared__ float red[LG_THREADS / WAVE];
-    for (size_t row = blockIdx.x; row < (size_t)rows; row += gridDim.x) {
+    // bw.xcd: every XCD (workgroups go to them by blockIdx mod 8; the grid is a multiple of 8) streams a contiguous
+    // eighth of the rows instead of every eighth row -- see dispatch_lsm
+    const size_t per_xcd = ((size_t)rows + 7) / 8;
+    const size_t items = bw.xcd ? per_xcd * 8 : (size_t)rows;
+    for (size_t it = blockIdx.x; it < items; it += gridDim.x) {
+    const size_t row = bw.xcd ? (it & 7) * per_xcd + (it >> 3) : it;
+    if (row >= (size_t)rows) continue;
     const float4* src = reinterpret_cast<const float4*>(x + row * V);
     const int nvec = V >> 2;
     float4 v[LG_MAXVEC];
@@ -438,11 +445,13 @@ constexpr int RG_UN = 2;          // groups per half and wave, loads first (1: 5
 #endif
 template <int KR, int NT>
 __global__ void __launch_bounds__(256) k_lsm_regs(const float* __restrict__ x, float* __restrict__ out,
-                                                  const int64_t ngroups, const int V) {
+                                                  const int64_t ngroups, const int V, const int xcd) {
     const int lane = threadIdx.x & 63, j = lane & 31, half = lane >> 5;
     const int g4 = (KR * V) >> 2;                  // float4 per group
     const bool act = j < g4;
-    const int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    // xcd: the eight XCDs (blockIdx mod 8; the grid is a multiple of 8) each stream a contiguous eighth of the groups
+    const unsigned wg = xcd ? (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3) : blockIdx.x;
+    const int64_t w = (int64_t)wg * 4 + (threadIdx.x >> 6);
     const lsm_f4* __restrict__ xin = reinterpret_cast<const lsm_f4*>(x);
     lsm_f4* __restrict__ xout = reinterpret_cast<lsm_f4*>(out);
     // the lane's four elements: the first `ns` of them belong to row r0 of the group, the rest to row r0 + 1
@@ -708,10 +717,16 @@ static hipError_t dispatch_lsm(hipStream_t stream, const float* x, float* out, c
         if (kr && rows >= kr) {
             const int64_t ngroups = rows / kr;
             const int64_t per_wg = 4 * RG_UN * 2;               // 4 waves x RG_UN groups x 2 halves
-            const int64_t grid = (ngroups + per_wg - 1) / per_wg;
+            int64_t grid = (ngroups + per_wg - 1) / per_wg;
+            // every XCD streams a contiguous eighth of the tensor (as the row-per-workgroup kernel below; here it costs two
+            // scalar instructions): V=50 1.44 GB equal, 5.76 GB 5.66 -> 5.86 TB/s, V=64 6.25 -> 6.40, 100 5.92 -> 6.19, 128
+            // 6.15 -> 6.44; the c4 step in bench.py 0.8759 / 0.8781 / 0.8779 -> 0.8726 / 0.8702 / 0.8709 ms, three
+            // interleaved pairs (profiles/r04_lsm_xcd_order_ab.txt).  RNNT_LSM_REGS_XCD=0: the plain order (A/B runs)
+            static const int regs_xcd = getenv("RNNT_LSM_REGS_XCD") ? atoi(getenv("RNNT_LSM_REGS_XCD")) : 1;
+            if (regs_xcd) grid = (grid + 7) / 8 * 8;
             if (grid < ((int64_t)1 << 31)) {
 #define LSM_REGS(KR) \
-    case KR: k_lsm_regs<KR, RNNT_LSM_REGS_NT><<<(unsigned)grid, 256, 0, stream>>>(x, out, ngroups, V); break;
+    case KR: k_lsm_regs<KR, RNNT_LSM_REGS_NT><<<(unsigned)grid, 256, 0, stream>>>(x, out, ngroups, V, regs_xcd); break;
                 switch (kr) { LSM_REGS(1) LSM_REGS(2) LSM_REGS(3) LSM_REGS(4) }
 #undef LSM_REGS
                 const hipError_t e = hipGetLastError();
@@ -817,7 +832,20 @@ static hipError_t dispatch_lsm(hipStream_t stream, const float* x, float* out, c
         }
 #undef LSM_SMALL
     } else if (aligned && V % 4 == 0 && V <= LG_MAXV) {
-        const unsigned grid = (unsigned)(rows < (1 << 22) ? rows : (1 << 22));
+        // Which rows an XCD streams (plain log-softmax only).  Workgroups go to the eight XCDs by blockIdx mod 8, so with
+        // row = work item every XCD reads every eighth row of one moving front; with bw.xcd each streams a contiguous
+        // eighth of the tensor.  Measured (tools/lsm_rate.py, TB/s in + out, every-eighth / contiguous, 1.92 GB in; 8 GB
+        // in brackets; profiles/r04_lsm_xcd_order_ab.txt): V=1500 5.9 / 6.2, 3000 6.0 / 6.2 [5.95 / 6.6], 5000 5.8-5.9 /
+        // 6.0-6.5 [5.7 / 6.1], 7168 6.2 / 6.4, 8192 6.0-6.2 / 6.3-6.4 [5.8 / 6.2], 16384 5.2-5.4 / 6.0 [5.3 / 6.2];
+        // nothing at 2048, 4096, 5120 ... 6144, 12288; WORSE for the three-pass covers of 2048 < V/4 <= 3072 (V=10000:
+        // 6.0 / 5.6 [5.9 / 5.6]), which keep the plain order.  RNNT_LG_XCD=0 / 1 forces one or the other (A/B runs).
+        static const int xcd_force = getenv("RNNT_LG_XCD") ? atoi(getenv("RNNT_LG_XCD")) : -1;
+        if constexpr (MODE == LSM_NORM) {
+            const int nv4 = V >> 2;
+            bw.xcd = xcd_force >= 0 ? (xcd_force != 0) : !(nv4 > 2048 && nv4 <= 3072);
+        }
+        unsigned grid = (unsigned)(rows < (1 << 22) ? rows : (1 << 22));
+        if (bw.xcd) grid = (grid + 7u) & ~7u;
 #ifdef RNNT_LG_PROBE
         if (const char* e = getenv("RNNT_LG_VARIANT")) {
             int th = 0, nv = 0;
