@@ -37,6 +37,22 @@ __device__ __forceinline__ float readlane(float v, int lane) {
 // 0 <= yn <= U-1 (binding.cpp:47-51; xn = 0 reads index -1, core.cu:343).  Checking on the host would
 // cost a device sync, so the check lives here: an utterance with out-of-range lengths is swept as a
 // one-cell lattice (no out-of-range access) and k_grads reports cost = NaN with zero gradients.
+// Which chunk of a streaming kernel's work an XCD takes.  Workgroups go to the eight XCDs by blockIdx mod 8: with
+// chunk = blockIdx every XCD works on every eighth chunk of one moving front; stream_block() renumbers the workgroups so
+// that XCD k streams the k-th contiguous eighth (grid = stream_grid(chunks): a multiple of 8; renumbered blocks beyond the
+// last chunk return).  Per kernel family, bit of RNNT_XCD_STREAM (measured per family: profiles/r04_lsm_xcd_order_ab.txt).
+#ifndef RNNT_XCD_STREAM
+#define RNNT_XCD_STREAM 15      // all four: c4, three interleaved pairs against -DRNNT_XCD_STREAM=0: fused forward 0.467 -> 0.464 ms,
+#endif                          // fused training step 0.978 -> 0.963, native log-softmax chain 1.86 -> 1.82, run_warp_rnnt 0.893 -> 0.879
+enum : int { XCD_LSM_SMALL = 1, XCD_EXPAND_SMALL = 2, XCD_LSMBWD_SMALL = 4, XCD_LSM_ROWS = 8 };
+template <int FAMILY> __device__ __forceinline__ unsigned stream_block() {
+    if constexpr ((RNNT_XCD_STREAM & FAMILY) != 0) return (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    else return blockIdx.x;
+}
+template <int FAMILY> inline unsigned stream_grid(unsigned chunks) {
+    return (RNNT_XCD_STREAM & FAMILY) != 0 ? (chunks + 7u) & ~7u : chunks;
+}
+
 struct UttLens {
     int Tn, Un;
     bool ok;

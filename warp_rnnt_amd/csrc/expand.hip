@@ -178,7 +178,9 @@ __global__ void __launch_bounds__(EX_THREADS)
 k_expand_small(const Rows rows, float* __restrict__ dense, unsigned cells, int R, int V, int blank) {
     extern __shared__ __attribute__((aligned(16))) float tile[];
     const int tid = threadIdx.x;
-    const unsigned cell0 = blockIdx.x * (unsigned)R;
+    const unsigned blk = stream_block<XCD_EXPAND_SMALL>();
+    if ((unsigned long long)blk * (unsigned)R >= cells) return;
+    const unsigned cell0 = blk * (unsigned)R;
     const int nrows = (int)min((unsigned)R, cells - cell0);
     const int nel = nrows * V;
     const int nvec = nel >> 2;
@@ -226,7 +228,8 @@ static hipError_t launch_rows(hipStream_t stream, const Rows& rows, float* dense
         int R = (EX_FLOATS / V) / 4 * 4;          // R % 4 == 0 keeps every tile start 16-byte aligned
         if (R < 4) R = 4;
         const size_t lds = (size_t)R * V * sizeof(float);
-        k_expand_small<Rows><<<(cells + R - 1) / R, EX_THREADS, lds, stream>>>(rows, dense, cells, R, V, blank);
+        k_expand_small<Rows><<<stream_grid<XCD_EXPAND_SMALL>((cells + R - 1) / R), EX_THREADS, lds, stream>>>(rows, dense, cells, R,
+                                                                                                       V, blank);
     } else {
         const unsigned grid = cells < (1u << 22) ? cells : (1u << 22);
         if (aligned && V % 4 == 0)

@@ -145,7 +145,8 @@ k_lsm_small(const float* x, float* out, const int* __restrict__ labels,
     extern __shared__ __attribute__((aligned(16))) float tile[];
     float2* stat = reinterpret_cast<float2*>(tile + (size_t)R * V);   // GATHER: (max, log-sum) per row
     const int tid = threadIdx.x;
-    const int64_t row0 = (int64_t)blockIdx.x * R;
+    const int64_t row0 = (int64_t)stream_block<XCD_LSM_SMALL>() * R;
+    if (row0 >= rows) return;
     const int nrows = (int)min((int64_t)R, rows - row0);
     const int nel = nrows * V;                      // floats in this chunk
     const float* src = x + row0 * V;                // 16-byte aligned: R % 4 == 0 (out may alias x)
@@ -610,7 +611,8 @@ k_lsm_rows(const float* x, float* out, const int* __restrict__ labels, int64_t r
     constexpr int UN = RowsShape<L>::UN, RW = RowsShape<L>::RW, RPW = RowsShape<L>::RPW;
     const int lane = threadIdx.x & 63, h = lane % L, rr = lane / L;
     // wave-uniform values kept in scalar registers (the 64-bit row arithmetic runs on the scalar unit)
-    const int64_t row0 = ((int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6)) * RPW;
+    const int64_t row0 = ((int64_t)stream_block<XCD_LSM_ROWS>() * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6)) * RPW;
+    if (row0 >= rows) return;
     const bool last_ok = (h + (Q - 1) * L) * VEC < V;   // the lane's last float4 is part of the row
     const bool whole = row0 + RPW <= rows;              // (uniform) every row of this wave exists
     const float* const wave_src = x + row0 * V;
@@ -783,8 +785,8 @@ static hipError_t dispatch_lsm(hipStream_t stream, const float* x, float* out, c
                 return hipGetLastError();
             }
             const int64_t rpw = L <= 8 ? 2 * (WAVE / L) : WAVE / L;       // RowsShape<L>::RPW
-            const int64_t grid = (rows + 4 * rpw - 1) / (4 * rpw);
-            if (grid < ((int64_t)1 << 31)) {
+            const int64_t grid = stream_grid<XCD_LSM_ROWS>((unsigned)((rows + 4 * rpw - 1) / (4 * rpw)));
+            if ((rows + 4 * rpw - 1) / (4 * rpw) < ((int64_t)1 << 31) - 8) {
 #define LSM_ROWS(LL, QQ) \
     if (L == LL && q == QQ) k_lsm_rows<LL, QQ><<<(unsigned)grid, 256, 0, stream>>>(x, out, labels, rows, V, T, U, blank);
 #define LSM_ROWS_L(LL) LSM_ROWS(LL, 1) LSM_ROWS(LL, 2) LSM_ROWS(LL, 3) LSM_ROWS(LL, 4)
@@ -816,7 +818,7 @@ static hipError_t dispatch_lsm(hipStream_t stream, const float* x, float* out, c
 #ifdef RNNT_LG_PROBE      // probe: fewer resident workgroups per CU (LDS the kernel does not use)
         if (const char* e = getenv("RNNT_LSM_LDS")) { const size_t want = (size_t)atoi(e); if (want > lds && want <= 65536) lds = want; }
 #endif
-        const unsigned grid = (unsigned)((rows + R - 1) / R);
+        const unsigned grid = stream_grid<XCD_LSM_SMALL>((unsigned)((rows + R - 1) / R));
 #define LSM_SMALL(LL)                                                                           \
     case LL:                                                                                    \
         if (wp && LL <= 16)                                                                     \
@@ -941,7 +943,8 @@ k_lsmbwd_small(const float* dy, const float* y, float* dx, int64_t rows, int V, 
     float* tdy = tile;
     float* ty = tile + (size_t)R * V;
     const int tid = threadIdx.x;
-    const int64_t row0 = (int64_t)blockIdx.x * R;
+    const int64_t row0 = (int64_t)stream_block<XCD_LSMBWD_SMALL>() * R;
+    if (row0 >= rows) return;
     const int nrows = (int)min((int64_t)R, rows - row0);
     const int nel = nrows * V, nvec = nel >> 2;
     const float* sdy = dy + row0 * V;
@@ -1031,7 +1034,7 @@ hipError_t launch_log_softmax_backward(hipStream_t stream, const float* dy, cons
         int R = (SMB_FLOATS / V) / 4 * 4;
         if (R < 4) R = 4;
         const size_t lds = (size_t)R * V * sizeof(float) * 2;
-        const unsigned grid = (unsigned)((rows + R - 1) / R);
+        const unsigned grid = stream_grid<XCD_LSMBWD_SMALL>((unsigned)((rows + R - 1) / R));
 #define LSMB_SMALL(LL) case LL: k_lsmbwd_small<LL><<<grid, SMB_THREADS, lds, stream>>>(dy, y, dx, rows, V, R, q); break;
         switch (L) { LSMB_SMALL(1) LSMB_SMALL(2) LSMB_SMALL(4) LSMB_SMALL(8) LSMB_SMALL(16) LSMB_SMALL(32) LSMB_SMALL(64) }
 #undef LSMB_SMALL
