@@ -842,9 +842,14 @@ static hipError_t dispatch_lsm(hipStream_t stream, const float* x, float* out, c
         // nothing at 2048, 4096, 5120 ... 6144, 12288; WORSE for the three-pass covers of 2048 < V/4 <= 3072 (V=10000:
         // 6.0 / 5.6 [5.9 / 5.6]), which keep the plain order.  RNNT_LG_XCD=0 / 1 forces one or the other (A/B runs).
         static const int xcd_force = getenv("RNNT_LG_XCD") ? atoi(getenv("RNNT_LG_XCD")) : -1;
+        // (fused gather / backward modes: no difference at c3 -- fused forward 0.3196 / 0.3184 / 0.3181 vs 0.3186 / 0.3178 /
+        //  0.3190 ms -- so they keep the plain order; RNNT_LG_XCD_FUSED=1 to try)
+        static const int xcd_fused = getenv("RNNT_LG_XCD_FUSED") ? atoi(getenv("RNNT_LG_XCD_FUSED")) : 0;
         if constexpr (MODE == LSM_NORM) {
             const int nv4 = V >> 2;
             bw.xcd = xcd_force >= 0 ? (xcd_force != 0) : !(nv4 > 2048 && nv4 <= 3072);
+        } else {
+            bw.xcd = xcd_fused;
         }
         unsigned grid = (unsigned)(rows < (1 << 22) ? rows : (1 << 22));
         if (bw.xcd) grid = (grid + 7u) & ~7u;
@@ -979,10 +984,14 @@ k_lsmbwd_small(const float* dy, const float* y, float* dx, int64_t rows, int V, 
 
 template <int LG_THREADS, int LG_MAXVEC>
 __global__ void __launch_bounds__(LG_THREADS)
-k_lsmbwd_large(const float* dy, const float* y, float* dx, int64_t rows, int V) {
+k_lsmbwd_large(const float* dy, const float* y, float* dx, int64_t rows, int V, int xcd) {
     __shared__ float red[LG_THREADS / WAVE];
     const int nvec = V >> 2;
-    for (size_t row = blockIdx.x; row < (size_t)rows; row += gridDim.x) {
+    const size_t per_xcd = ((size_t)rows + 7) / 8;       // (xcd: as k_lsm_large)
+    const size_t items = xcd ? per_xcd * 8 : (size_t)rows;
+    for (size_t it = blockIdx.x; it < items; it += gridDim.x) {
+        const size_t row = xcd ? (it & 7) * per_xcd + (it >> 3) : it;
+        if (row >= (size_t)rows) continue;
         const float4* sdy = reinterpret_cast<const float4*>(dy + row * V);
         const float4* sy = reinterpret_cast<const float4*>(y + row * V);
         float4 g[LG_MAXVEC];
@@ -1039,20 +1048,25 @@ hipError_t launch_log_softmax_backward(hipStream_t stream, const float* dy, cons
         switch (L) { LSMB_SMALL(1) LSMB_SMALL(2) LSMB_SMALL(4) LSMB_SMALL(8) LSMB_SMALL(16) LSMB_SMALL(32) LSMB_SMALL(64) }
 #undef LSMB_SMALL
     } else if (aligned && V % 4 == 0 && V <= LG_MAXV) {
-        const unsigned grid = (unsigned)(rows < (1 << 22) ? rows : (1 << 22));
+        // every XCD streams a contiguous eighth of the rows (as the forward kernel, dispatch_lsm): the reference's call
+        // chain with the native log-softmax function at c3 2.08 / 2.07 / 2.03 -> 2.03 / 2.03 / 1.99 ms per training step;
+        // RNNT_LSMBWD_XCD=0: the plain order (A/B runs)
+        static const int bxcd = getenv("RNNT_LSMBWD_XCD") ? atoi(getenv("RNNT_LSMBWD_XCD")) : 1;
+        unsigned grid = (unsigned)(rows < (1 << 22) ? rows : (1 << 22));
+        if (bxcd) grid = (grid + 7u) & ~7u;
         static const bool old_rule = getenv("RNNT_LSMBWD_SMALLEST_COVER") != nullptr;    // (A/B knob)
         if (old_rule) {
-            if (V <= 4096) k_lsmbwd_large<256, 4><<<grid, 256, 0, stream>>>(dy, y, dx, rows, V);
-            else if (V <= 8192) k_lsmbwd_large<256, 8><<<grid, 256, 0, stream>>>(dy, y, dx, rows, V);
-            else k_lsmbwd_large<512, 8><<<grid, 512, 0, stream>>>(dy, y, dx, rows, V);
+            if (V <= 4096) k_lsmbwd_large<256, 4><<<grid, 256, 0, stream>>>(dy, y, dx, rows, V, bxcd);
+            else if (V <= 8192) k_lsmbwd_large<256, 8><<<grid, 256, 0, stream>>>(dy, y, dx, rows, V, bxcd);
+            else k_lsmbwd_large<512, 8><<<grid, 512, 0, stream>>>(dy, y, dx, rows, V, bxcd);
         } else {      // as the forward kernel (dispatch_lsm): two or three passes, (nearly) every thread busy
             const int nvec = V >> 2;
             const int passes = nvec <= 2048 ? 2 : 3;
             int th = (nvec + 128 * passes - 1) / (128 * passes) * 128;
             th = th < 256 ? 256 : th;
-#define LGB(TH, NV) case TH: k_lsmbwd_large<TH, NV><<<grid, TH, 0, stream>>>(dy, y, dx, rows, V); break;
+#define LGB(TH, NV) case TH: k_lsmbwd_large<TH, NV><<<grid, TH, 0, stream>>>(dy, y, dx, rows, V, bxcd); break;
             if (nvec > 3072) {
-                k_lsmbwd_large<512, 8><<<grid, 512, 0, stream>>>(dy, y, dx, rows, V);
+                k_lsmbwd_large<512, 8><<<grid, 512, 0, stream>>>(dy, y, dx, rows, V, bxcd);
             } else if (passes == 2) {
                 switch (th) { LGB(256, 2) LGB(384, 2) LGB(512, 2) LGB(640, 2) LGB(768, 2) LGB(896, 2) LGB(1024, 2) }
             } else {
