@@ -17,6 +17,8 @@
 #include <algorithm>
 
 #include "common.h"
+#include <type_traits>
+
 #include "kernels.h"
 
 namespace rnnt {
@@ -178,6 +180,56 @@ k_lsm_small(const float* x, float* out, const int* __restrict__ labels,
     const int h = tid % L, rr = tid / L;
     const int ctail = h + (q - 1) * L;              // this lane's last column, may be >= V
     const bool tail_ok = ctail < V;
+    // One row: the lane's q values are read ONCE into registers by a straight-line sequence (all LDS reads in flight
+    // together), reduced, and -- in the modes that rewrite the row -- written back from the registers.  QC = q as a
+    // compile-time constant (9 ... 16: what the launcher's choice of L gives for V > 16); the run-time loops of the first
+    // version waited for every LDS read of the max pass on its own (~9 instructions and one LDS latency per element) and
+    // read every element a second time for the sum.
+    auto one_row = [&](auto QC, const int r) {
+        constexpr int Q = decltype(QC)::value;
+        float* row = tile + r * V;
+        float v[Q];
+#pragma unroll
+        for (int i = 0; i < Q - 1; ++i) v[i] = row[h + i * L];
+        v[Q - 1] = tail_ok ? row[ctail] : -__builtin_inff();
+        float mx = v[0];
+#pragma unroll
+        for (int i = 1; i < Q; ++i) mx = fmaxf(mx, v[i]);
+        mx = group_max<L>(mx);
+        const float mb = -mx * LOG2E;
+        float s = 0.0f;
+#pragma unroll
+        for (int i = 0; i < Q; ++i) s += __builtin_amdgcn_exp2f(__builtin_fmaf(v[i], LOG2E, mb));   // (exp2(-inf) = 0)
+        s = group_sum<L>(s);
+        const float ls = __builtin_amdgcn_logf(s) * LN2;
+        if constexpr (GATHER) {
+            if (h == 0) stat[r] = make_float2(mx, ls);
+        } else if constexpr (MODE == LSM_BWD) {
+            const CellMap m = map_cell((size_t)(row0 + r), labels, T, U, V, blank);
+            const float sc = bw.scale ? bw.scale[m.n] : 1.0f;
+            const float2 g = bw.g2[m.sk];
+            const float gB = g.x * sc, gL = g.y * sc, gs = gB + gL;
+            const float mb2 = -(mx + ls) * LOG2E;
+#pragma unroll
+            for (int i = 0; i < Q - 1; ++i)
+                row[h + i * L] = -__builtin_amdgcn_exp2f(__builtin_fmaf(v[i], LOG2E, mb2)) * gs;
+            if (tail_ok) row[ctail] = -__builtin_amdgcn_exp2f(__builtin_fmaf(v[Q - 1], LOG2E, mb2)) * gs;
+            // the L lanes of a row sit in one wave and LDS operations of a wave retire in order
+            if (h == 0) { row[blank] += gB; row[m.label] += gL; }
+        } else {
+#pragma unroll
+            for (int i = 0; i < Q - 1; ++i) row[h + i * L] = (v[i] - mx) - ls;
+            if (tail_ok) row[ctail] = (v[Q - 1] - mx) - ls;
+        }
+    };
+    auto all_rows = [&](auto QC) {
+        for (int r = rr; r < nrows; r += RPP) one_row(QC, r);
+    };
+    switch (q) {
+#define LSM_Q(QQ) case QQ: all_rows(std::integral_constant<int, QQ>{}); break;
+        LSM_Q(9) LSM_Q(10) LSM_Q(11) LSM_Q(12) LSM_Q(13) LSM_Q(14) LSM_Q(15) LSM_Q(16)
+#undef LSM_Q
+        default:      // q <= 8 (V <= 16, or rows shorter than the lane cover): run-time loops
     for (int r = rr; r < nrows; r += RPP) {
         float* row = tile + r * V;
         float mx = -__builtin_inff();
@@ -207,6 +259,7 @@ k_lsm_small(const float* x, float* out, const int* __restrict__ labels,
             for (int i = 0, c = h; i < q - 1; ++i, c += L) row[c] = (row[c] - mx) - ls;
             if (tail_ok) row[ctail] = (row[ctail] - mx) - ls;
         }
+    }
     }
     if constexpr (GATHER && WP) {
         wave_sync_lds();
@@ -745,7 +798,8 @@ static hipError_t dispatch_lsm(hipStream_t stream, const float* x, float* out, c
         // V=256 5.82 -> 6.44, 496 5.33 -> 6.12, 500 5.14 -> 5.90, 512 5.77 -> 6.47, 768 5.58 -> 6.15, 980 5.26 -> 6.00,
         // 1000 5.14 -> 6.10, 1024 5.76 -> 6.59; with 94 % of the lanes busy still +4 ... +10 % (484, 724, 964), below
         // that -- and below 98 % for a single wave (V=244: 5.53 -> 5.23) -- the tiles win (V=200, 400, 600: 78 / 59 %).
-        if (aligned && V % 4 == 0 && V > 128 && V <= 1024) {
+        static const bool no_lgr = getenv("RNNT_LSM_NO_LGR") != nullptr;    // A/B runs: the LDS-staged kernel instead
+        if (aligned && !no_lgr && V % 4 == 0 && V > 128 && V <= 1024) {
             const int nvec = V >> 2, th = (nvec + 63) / 64 * 64;
             const unsigned grid = (unsigned)(rows < (1 << 22) ? rows : (1 << 22));
 #define LGR(TH, NV) { k_lsm_large<MODE, TH, NV><<<grid, TH, 0, stream>>>(x, out, labels, rows, V, T, U, blank, bw); return hipGetLastError(); }
@@ -761,19 +815,21 @@ static hipError_t dispatch_lsm(hipStream_t stream, const float* x, float* out, c
         }
     }
     if constexpr (MODE == LSM_GATHER) {
-        // Rows in registers, L lanes per row, where the rows are whole 128-byte lines (V % 32 == 0: 32 ... 1024) or long
-        // enough for a row instruction (32 / 64 lanes x 16 bytes) not to mind where the lines start (V % 4 == 0 above
-        // 256).  Forward of the fused entry, N=32, T=500, U=100, us, this kernel / LDS tiles (tools/fused_rate.py,
-        // profiles/r04_lsm_rows_ab.txt): V=32 97 / 158, 64 134 / 170, 96 174 / 178, 128 191-205 / 211-225, 160 260 / 284,
-        // 256 306-321 / 353-359, 400 505 / 586, 512 622 / 655, 600 725 / 901, 800 824 / 1125, 1000 1052 / 1312, 1024 1057 /
-        // 1241; not where an 8- or 16-lane row instruction straddles lines (V=100: 236 / 187, 132: 281 / 257, 200: 327 /
-        // 323) and not with float2 rows for V % 4 == 2 (V=50: 169 / 132 -- c4's lattice: 664 / 465).
+        // Rows in registers, L lanes per row (k_lsm_rows), against the LDS-staged kernel below -- re-measured after that
+        // kernel got its straight-line row pass (forward of the fused entry, N=32, T=500, U=100, us, k_lsm_rows / LDS tiles;
+        // tools/fused_rate.py, profiles/r04_lsm_rows_ab.txt section 9): V=32 97 / 127, 64 140 / 146, 128 187 / 197, 256 320 /
+        // 341, 320 393 / 404; 448 512 / 522, 480 532 / 554, 500 561 / 583, 512 505 / 587, 544 609 / 753, 640 668 / 749, 768
+        // 791 / 812, 896 850 / 930, 1000 986 / 1089, 1024 1016 / 1128; but 96 180 / 163, 160 256 / 237, 192 285 / 262, 224 302 /
+        // 290, 352 426 / 418, 384 456 / 426, 400 510 / 485, and everything whose 8- or 16-lane row instructions straddle
+        // lines (V=100: 236 / 187, 132: 281 / 257) or needs float2 rows (V=50: 169 / 132).  Rule: the powers of two from 32
+        // to 256, and every V % 4 == 0 from 448 on.
         // (RNNT_LSM_NO_ROWS=1: the LDS-staged kernel, for A/B runs; RNNT_LSM_NO_DIAG=1: consecutive rows per wave for
         //  every V; RNNT_LSM_ROWS_ANY=1: this kernel for every V % 4 == 0)
         static const bool no_rows = getenv("RNNT_LSM_NO_ROWS") != nullptr;
         static const bool no_diag = getenv("RNNT_LSM_NO_DIAG") != nullptr;
         static const bool rows_any = getenv("RNNT_LSM_ROWS_ANY") != nullptr;
-        if (aligned && !no_rows && V % 4 == 0 && V >= 32 && V <= 1024 && (V % 32 == 0 || V > 256 || rows_any)) {
+        const bool rows_rule = V == 32 || V == 64 || V == 128 || V == 256 || V >= 448;
+        if (aligned && !no_rows && V % 4 == 0 && V >= 32 && V <= 1024 && (rows_rule || rows_any)) {
             int L = 8;
             while (L < 64 && L * 16 < V) L <<= 1;
             const int q = (V / 4 + L - 1) / L;         // 1 ... 4
