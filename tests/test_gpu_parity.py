@@ -227,12 +227,13 @@ def test_calls_stress():
 # ----------------------------------------------------------------------------
 # (1024 / 2048 / 3072 / 4096 / 5632 / 6144 / 8192 / 12288 / 16384: where the launcher changes kernel or workgroup
 #  shape, prologue.hip: dispatch_lsm, each with its neighbour on the other side;
-#  20 ... 128: the rows-in-registers kernel with 1, 2, 3 and 4 rows per group -- 28 / 50 are c2 / c4 -- and its
-#  neighbours that fall back to the LDS-staged one; 1003 rows: a tail that is no whole group;
+#  32 ... 128: the rows-in-registers kernel with 1, 2, 3 and 4 rows per group -- 50 is c4 -- and its neighbours that
+#  fall back to the LDS-staged one (below 32 -- c2's 28 -- always: its straight-line row pass for 9 ... 16 columns per
+#  lane, the run-time loops below that); 1003 rows: a tail that is no whole group;
 #  132 ... 1024: the row-in-registers kernel with small workgroups where a row fills its cover (252, 256, 484, 500, 512,
 #  724, 768, 964, 1000, 1024) and the LDS-staged one where it does not (132, 244, 248, 480, 600, 720, 960);
-#  136, 160, 192: LDS-staged with the rotated column walk (rows on the same banks))
-@pytest.mark.parametrize("V", [2, 3, 5, 20, 24, 28, 30, 32, 40, 42, 48, 50, 51, 64, 80, 100, 126, 128, 132, 136, 160, 192,
+#  136, 160, 192: LDS-staged, rows on the same banks)
+@pytest.mark.parametrize("V", [2, 3, 5, 9, 13, 16, 17, 20, 24, 28, 30, 32, 33, 36, 40, 42, 48, 50, 51, 64, 80, 100, 126, 128, 132, 136, 160, 192,
                                200, 244, 248, 252, 256,
                                257, 480, 484, 500, 512, 600, 720, 724, 768, 960, 964, 1000, 1024, 1028,
                                1030, 2048, 2052, 2560, 2564, 3072, 3076, 4096, 4100, 5000, 5120, 5124, 5632, 5636,

@@ -768,7 +768,10 @@ static hipError_t dispatch_lsm(hipStream_t stream, const float* x, float* out, c
     if constexpr (MODE == LSM_NORM) {
         // rows in registers where the vocabulary allows it (RNNT_LSM_NO_REGS=1: the LDS-staged kernel, for A/B runs)
         static const bool no_regs = getenv("RNNT_LSM_NO_REGS") != nullptr;
-        const int kr = (aligned && !no_regs) ? lsm_regs_rows_per_group(V) : 0;
+        // (below V = 32 -- four rows per group -- the LDS-staged kernel with its straight-line row pass is the faster one
+        //  since round 4: the c4 lattice with V=24 0.584 -> 0.536 ms per step, V=28 0.589-0.605 -> 0.584, c2 0.0343 -> 0.0336;
+        //  from V = 32 on this kernel wins inside the step: V=40 0.71 vs 0.73, V=50 0.870 vs 0.893; tools/step_rate.py)
+        const int kr = (aligned && !no_regs && V >= 32) ? lsm_regs_rows_per_group(V) : 0;
         if (kr && rows >= kr) {
             const int64_t ngroups = rows / kr;
             const int64_t per_wg = 4 * RG_UN * 2;               // 4 waves x RG_UN groups x 2 halves
