@@ -203,6 +203,7 @@ def test_hip_graph_capture_and_replay():
 
 
 @pytest.mark.parametrize("shape", [(1000, 50), (37, 5000), (64, 1030), (5, 7, 3, 28), (11, 2), (33, 2560), (33, 2564),
+                                   (300, 17), (300, 36), (300, 100), (300, 128), (300, 200), (300, 500), (70, 1000),
                                    (21, 5124), (9, 10000), (9, 12292), (5, 16384), (3, 17000)])
 def test_log_softmax_autograd(shape):
     from warp_rnnt_amd.functional import log_softmax

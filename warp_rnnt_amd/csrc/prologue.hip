@@ -1023,6 +1023,32 @@ k_lsmbwd_small(const float* dy, const float* y, float* dx, int64_t rows, int V, 
     const int h = tid % L, rr = tid / L;
     const int ctail = h + (q - 1) * L;
     const bool tail_ok = ctail < V;
+    // (q = 9 ... 16 as a compile-time constant: both rows read once into registers by straight-line code, as k_lsm_small)
+    auto all_rows = [&](auto QC) {
+        constexpr int Q = decltype(QC)::value;
+        for (int r = rr; r < nrows; r += RPP) {
+            float* rdy = tdy + r * V;
+            const float* ry = ty + r * V;
+            float g[Q], yv[Q];
+#pragma unroll
+            for (int i = 0; i < Q - 1; ++i) { g[i] = rdy[h + i * L]; yv[i] = ry[h + i * L]; }
+            g[Q - 1] = tail_ok ? rdy[ctail] : 0.0f;
+            yv[Q - 1] = tail_ok ? ry[ctail] : 0.0f;
+            float s = 0.0f;
+#pragma unroll
+            for (int i = 0; i < Q; ++i) s += g[i];
+            s = group_sum<L>(s);
+#pragma unroll
+            for (int i = 0; i < Q - 1; ++i)
+                rdy[h + i * L] = __builtin_fmaf(-__builtin_amdgcn_exp2f(yv[i] * LOG2E), s, g[i]);
+            if (tail_ok) rdy[ctail] = __builtin_fmaf(-__builtin_amdgcn_exp2f(yv[Q - 1] * LOG2E), s, g[Q - 1]);
+        }
+    };
+    switch (q) {
+#define LSMB_Q(QQ) case QQ: all_rows(std::integral_constant<int, QQ>{}); break;
+        LSMB_Q(9) LSMB_Q(10) LSMB_Q(11) LSMB_Q(12) LSMB_Q(13) LSMB_Q(14) LSMB_Q(15) LSMB_Q(16)
+#undef LSMB_Q
+        default:
     for (int r = rr; r < nrows; r += RPP) {
         float* rdy = tdy + r * V;
         const float* ry = ty + r * V;
@@ -1033,6 +1059,7 @@ k_lsmbwd_small(const float* dy, const float* y, float* dx, int64_t rows, int V, 
         for (int i = 0, c = h; i < q - 1; ++i, c += L)
             rdy[c] = __builtin_fmaf(-__builtin_amdgcn_exp2f(ry[c] * LOG2E), s, rdy[c]);
         if (tail_ok) rdy[ctail] = __builtin_fmaf(-__builtin_amdgcn_exp2f(ry[ctail] * LOG2E), s, rdy[ctail]);
+    }
     }
     __syncthreads();
     float* dst = dx + row0 * V;
