@@ -132,8 +132,9 @@ def test_non_default_stream_and_device_guard():
     np.testing.assert_allclose(tot.item(), ref["costs"].sum(), rtol=1e-5)
 
 
-# V % 32 == 0, and V % 4 == 0 above 256: the rows-in-registers fused gather (prologue.hip: k_lsm_rows, 8 ... 64 lanes per
-# row, ragged last float4; k_lsm_rows_diag for V = 32, 64 and its T < 16 fallback); the others stay on the LDS tiles
+# V = 32, 64, 128, 256 and V % 4 == 0 from 448 on: the rows-in-registers fused gather (prologue.hip: k_lsm_rows, 8 ... 64
+# lanes per row, ragged last float4; k_lsm_rows_diag for V = 32, 64 and its T < 16 fallback); the others stay on the LDS
+# tiles (straight-line row pass for 9 ... 16 columns per lane: 34 ... 258 here; run-time loops below: V=7)
 @pytest.mark.parametrize("N,Tm,Um,V", [(3, 30, 12, 50), (2, 9, 5, 5000), (2, 11, 70, 7), (2, 6, 4, 1030),
                                        (3, 40, 21, 128), (2, 33, 9, 64), (2, 21, 12, 32), (2, 17, 14, 80),
                                        (2, 17, 14, 96), (2, 19, 8, 160), (2, 19, 8, 192), (2, 19, 8, 256),
