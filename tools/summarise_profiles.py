@@ -89,7 +89,7 @@ def main():
     # system moves the whole 128-byte line -- profiles/<tag>_rocprof_probe_fetch_size.csv, the stride probes of
     # tools/ubench/gather_variants.hip run as long as a full read -- so FETCH_SIZE is doubled here too)
     def gpick(counter):
-        ks = [k for k in gagg if "k_to_diagonal<true>" in k[0].replace(" ", "") and k[1] == counter]
+        ks = [k for k in gagg if "k_to_diagonal<true" in k[0].replace(" ", "") and k[1] == counter]
         return sum(gagg[ks[0]]) / len(gagg[ks[0]]) if ks else None
     gf, gw = gpick("FETCH_SIZE"), gpick("WRITE_SIZE")
     if gf is not None and gw is not None:
