@@ -398,3 +398,17 @@ def test_reference_binding_links_against_this_library(tmp_path):
     e = torch.tensor([], dtype=torch.int)
     with pytest.raises(RuntimeError, match="xs must be located in the CUDA"):
         mod.rnnt_loss(torch.tensor([], dtype=torch.float32), e, e, e, 0, 0.0)
+
+
+def test_committed_traffic_file_has_what_bench_reads():
+    """bench.py labels `roofline.traffic` / `roofline_gather.traffic` with the committed counter collection
+    (profiles/hbm_traffic.json, written by tools/summarise_profiles.py): the entries it looks up must be there, each with
+    its source, and within a factor two of the algorithmic bytes they are compared with."""
+    import json
+    doc = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json")))
+    algorithmic = {"c4": 2.88e9, "c3": 3.84e9, "c4_gather": 1.31e9 + 0.0576e9}
+    for key, alg in algorithmic.items():
+        rec = doc[key]
+        assert rec["source"] and rec["kernel"], key
+        assert 0.9 * alg < rec["traffic_bytes"] < 2.0 * alg, (key, rec["traffic_bytes"])
+
