@@ -4,11 +4,15 @@
  * DEVICE pointer unless stated otherwise; every call only ENQUEUES work on
  * `stream` (no allocation, no host synchronisation), so the library is
  * re-entrant across streams and threads.  State the library keeps, all of it
- * harmless to share: the lattice route (rnnt_amd_set_lattice: one atomic int,
+ * harmless to share: the lattice route and the log-domain kernel override
+ * (rnnt_amd_set_lattice, rnnt_amd_set_logdomain_kernel: one atomic int each,
  * read once per call), a launch counter per process and one per device (they
- * only make the hand-over tags of the probability-domain lattice kernel unique
- * per launch and per graph replay), a few A/B knobs read once from the
- * environment (RNNT_LSM_NO_REGS, RNNT_LSM_NO_WP, RNNT_LSMBWD_SMALLEST_COVER), a per-thread status
+ * only make the hand-over tags of the column-block lattice kernels unique
+ * per launch and per graph replay), kernel-selection knobs for A/B runs, each
+ * read once from the environment and none of them changing a result beyond
+ * fp32 rounding of the log-softmax (RNNT_LSM_*, RNNT_LG_*, RNNT_LSMBWD_*,
+ * RNNT_GATHER_*, RNNT_COMPACT_*, RNNT_DENSE_ONE_LAUNCH_CELLS, RNNT_WD_LONE_FROM_T:
+ * the table in DESIGN.md section 10), a per-thread status
  * for the void-returning compact entry points (rnnt_amd_compact_last_status)
  * and a once-per-process kernel attribute.  Nothing depends on what an earlier
  * call left in a workspace: scratch contents are unspecified on entry and exit.
