@@ -1594,18 +1594,37 @@ k_compact_offsets(const int* __restrict__ xn, const int* __restrict__ yn, int N,
     }
     if ((tid & (WAVE - 1)) == 0) { s_tmax[tid >> 6] = tmax; s_umax[tid >> 6] = umax; }
     __syncthreads();
-    // Hillis-Steele inclusive scan over the 1024 per-thread totals
-    for (int o = 1; o < CP_THREADS; o <<= 1) {
-        int64_t vc = 0;
-        int vl = 0;
-        if (tid >= o) { vc = s_cells[tid - o]; vl = s_labs[tid - o]; }
-        __syncthreads();
-        s_cells[tid] += vc;
-        s_labs[tid] += vl;
-        __syncthreads();
+    // inclusive scan over the 1024 per-thread totals: inside every wave on shuffles, then the sixteen wave totals by the
+    // first wave -- two barriers (the first version's Hillis-Steele over shared memory took twenty)
+    __shared__ int64_t s_wc[CP_THREADS / WAVE];
+    __shared__ int s_wl[CP_THREADS / WAVE];
+    const int lane = tid & (WAVE - 1), wv = tid >> 6;
+    int64_t ic = c;
+    int il = l;
+    for (int o = 1; o < WAVE; o <<= 1) {
+        const int64_t vc = __shfl_up(ic, o);
+        const int vl = __shfl_up(il, o);
+        if (lane >= o) { ic += vc; il += vl; }
     }
-    int64_t cbase = s_cells[tid] - c;     // exclusive
-    int lbase = s_labs[tid] - l;
+    if (lane == WAVE - 1) { s_wc[wv] = ic; s_wl[wv] = il; }
+    __syncthreads();
+    if (wv == 0) {
+        int64_t wc = lane < CP_THREADS / WAVE ? s_wc[lane] : 0;
+        int wl = lane < CP_THREADS / WAVE ? s_wl[lane] : 0;
+        for (int o = 1; o < CP_THREADS / WAVE; o <<= 1) {
+            const int64_t vc = __shfl_up(wc, o);
+            const int vl = __shfl_up(wl, o);
+            if (lane >= o) { wc += vc; wl += vl; }
+        }
+        if (lane < CP_THREADS / WAVE) { s_wc[lane] = wc; s_wl[lane] = wl; }   // inclusive totals of waves 0 ... lane
+    }
+    __syncthreads();
+    if (wv > 0) { ic += s_wc[wv - 1]; il += s_wl[wv - 1]; }
+    s_cells[tid] = ic;
+    s_labs[tid] = il;
+    __syncthreads();
+    int64_t cbase = ic - c;     // exclusive
+    int lbase = il - l;
     for (int n = lo; n < hi; ++n) {
         cell_offs[n] = cbase;
         label_offs[n] = lbase;
