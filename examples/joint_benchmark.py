@@ -45,7 +45,8 @@ class JointNetwork(nn.Module):
     def forward(self, f, g, f_len=None, g_len=None):
         if self.packed:
             H = f.size(-1)
-            rows = [(f[n, :int(f_len[n])].unsqueeze(1) + g[n, :int(g_len[n]) + 1].unsqueeze(0)).reshape(-1, H)
+            fl, gl = f_len.tolist(), g_len.tolist()          # one read-back each, not one per utterance
+            rows = [(f[n, :fl[n]].unsqueeze(1) + g[n, :gl[n] + 1].unsqueeze(0)).reshape(-1, H)
                     for n in range(f.size(0))]
             x = torch.cat(rows, dim=0)
         else:
@@ -78,8 +79,10 @@ def pick_loss(name):
         return lambda xs, ys, xn, yn: rnnt_loss(xs, ys, xn, yn, gather=True)
     if name == "warp-rnnt-compact":
         def compact(xs, ys, xn, yn):
-            packed = torch.cat([ys[n, :int(yn[n])] for n in range(ys.size(0))])
-            return rnnt_loss(xs, packed, xn, yn, compact=True)
+            yl = yn.tolist()
+            packed = torch.cat([ys[n, :yl[n]] for n in range(ys.size(0))])
+            # the padded tensors' own sizes are launch bounds: the loss itself then needs no read-back
+            return rnnt_loss(xs, packed, xn, yn, compact=True, max_frames=int(max(xn.tolist())), max_labels=ys.size(1))
         return compact
     if name == "warp-rnnt-fused":
         return lambda xs, ys, xn, yn: rnnt_loss_from_logits(xs, ys, xn, yn)
