@@ -156,6 +156,15 @@ rnntStatus_t rnnt_amd_loss(rnntStream_t stream, void *workspace, int input_kind,
                            int grads_kind, int N, int T, int U, int V, int blank,
                            float fastemit_lambda);
 
+/* The same call with the arithmetic of the alpha / beta sweeps chosen for THIS call: `lattice` = 0 auto, 1 logdomain,
+ * 2 pd (the values of rnnt_amd_set_lattice below), or RNNT_LATTICE_DEFAULT = whatever rnnt_amd_set_lattice last set --
+ * which is what rnnt_amd_loss passes.  No state is read or written: threads that want different routes use this. */
+#define RNNT_LATTICE_DEFAULT (-1)
+rnntStatus_t rnnt_amd_loss_ex(rnntStream_t stream, void *workspace, int input_kind, const float *input,
+                              const int *labels, const int *xn, const int *yn, float *costs, float *grads,
+                              int grads_kind, int N, int T, int U, int V, int blank,
+                              float fastemit_lambda, int lattice);
+
 /*
  * Backward of the gather prologue (warp_rnnt/__init__.py:21-24,126): expands
  * RNNT_GRADS_GATHERED_DIAGONAL gradients, scaled by grad_costs[n] (NULL = 1), into a dense
@@ -192,6 +201,13 @@ rnntStatus_t rnnt_amd_loss_compact(rnntStream_t stream, void *workspace, const f
                                    const int *label_offsets, float *costs, float *grads2, int64_t *loc,
                                    int N, int64_t STU, int Tmax, int Umax, int V, int blank,
                                    float fastemit_lambda);
+
+/* ... with the lattice route of this call (see rnnt_amd_loss_ex) */
+rnntStatus_t rnnt_amd_loss_compact_ex(rnntStream_t stream, void *workspace, const float *xs, const int *ys,
+                                      const int *xn, const int *yn, const int64_t *cell_offsets,
+                                      const int *label_offsets, float *costs, float *grads2, int64_t *loc,
+                                      int N, int64_t STU, int Tmax, int Umax, int V, int blank,
+                                      float fastemit_lambda, int lattice);
 
 /* The same in ONE call with launch bounds the caller supplies (Tmax >= every xn, Umax >= every yn + 1; n_labels = the
  * number of elements of ys): offsets, maxima and the shape checks stay on the device, nothing is read back, so the call
@@ -264,8 +280,10 @@ size_t rnnt_amd_debug_redo_offset(int N, int T, int U);
  *                on long lattices -- the log domain accumulates ~ulp(|alpha|) per step (1e-2 on the gradients at T=1500,
  *                U=300, the reference's included), the probability domain does not (7e-4) -- at the reference's speed
  *                or better only while 2N*ceil(U/64) <= the number of compute units.
- * Process-wide, read once per call, may be changed at any time (not thread-safe: concurrent callers that want different
- * routes must serialise); the initial value comes from the environment variable RNNT_LATTICE (logdomain | pd).  The
+ * Process-wide, read once per call, may be changed at any time: the DEFAULT of every call that does not name a route
+ * itself.  Callers on several threads that want different routes pass theirs per call -- rnnt_amd_loss_ex /
+ * rnnt_amd_loss_compact_ex, `lattice=` in warp_rnnt_amd.ops -- and leave this setting alone.
+ * The initial value comes from the environment variable RNNT_LATTICE (logdomain | pd).  The
  * reference-named entry points of Part 1 always run the log domain.  Returns the previous setting, or -1 for an
  * unknown value.
  */
@@ -276,9 +294,11 @@ int rnnt_amd_get_lattice(void);
  * Which KERNEL serves the log-domain arithmetic where two can (speed only -- they share the step function and produce
  * the same bits, tests/test_gpu_wd.py):
  *   0 by shape   (default)
- *   1 ws         all column blocks of a sweep in one workgroup (csrc/lattice_ws.hip; U <= 512)
+ *   1 ws         all column blocks of a sweep in one workgroup, one compute + one I/O wave each (csrc/lattice_ws.hip; U <= 512)
  *   2 wd         one workgroup per 64-column block, boundary columns through L2 rings (csrc/lattice_wd.hip; any U)
- * Process-wide, read once per call; initial value from the environment variable RNNT_LOGDOMAIN_KERNEL (ws | wd).
+ *   3 wl         the single-workgroup form of wd (k_lattice_wl: three waves per column block, boundary columns through
+ *                LDS), wherever the workgroup's LDS holds the lattice's column blocks
+ * Process-wide, read once per call; initial value from the environment variable RNNT_LOGDOMAIN_KERNEL (ws | wd | wl).
  * Returns the previous setting, or -1 for an unknown value.  A tuning and test knob, not part of the numerics contract.
  */
 int rnnt_amd_set_logdomain_kernel(int kernel);
@@ -286,7 +306,8 @@ int rnnt_amd_get_logdomain_kernel(void);
 
 /* Diagnostics (bench.py's `lattice_route`, tests): the lattice kernel the calling thread's last loss call launched --
  * 1 lattice_ws (log domain, one workgroup per sweep), 2 lattice_wd (log domain, one per column block), 3 lattice_pd
- * (probability domain), 4 the single-role kernel of lattice.hip (reference layouts, stripes); 0 before the first call. */
+ * (probability domain), 4 the single-role kernel of lattice.hip (reference layouts, stripes), 5 lattice_wl (log domain,
+ * one workgroup per sweep, the wave roles of lattice_wd); 0 before the first call. */
 int rnnt_amd_debug_last_lattice_kernel(void);
 
 /* Library version, for the host-side loader. */

@@ -232,6 +232,41 @@ def test_reference_named_compact_entry_points():
     assert L.rnnt_amd_compact_last_status() == 5 and L.rnnt_amd_compact_last_status() == 0
 
 
+@pytest.mark.parametrize("N,Tm,Um,V,kernel", [
+    (40, 500, 60, 5, "lattice_wd"),        # one column block: the plain launch of the column-block kernel
+    (20, 500, 110, 5, "lattice_wl"),       # two: its single-workgroup form
+    (6, 420, 430, 4, "lattice_ws"),        # seven: lattice_ws.hip on 32-bit offsets
+])
+def test_reference_named_compact_entry_points_staged(N, Tm, Um, V, kernel):
+    """From 2^20 cells of launch bound on run_warp_rnnt_compact turns the row-major pairs into per-utterance
+    diagonal-major planes inside the caller's `grads`, sweeps on the tuned kernels and turns the gradient pairs back
+    (csrc/api.hip).  Against the oracle, ragged, FastEmit; bit-equal to the native compact entry, which runs the same
+    kernels on 64-bit offsets."""
+    import warp_rnnt_amd
+    import warp_rnnt._C as core
+    assert N * Tm * Um >= 1 << 20
+    lam = 0.01
+    logits, labels, xn, yn = make_case(300 + Um, N, Tm, Um, V, ragged=True)
+    yn[1] = 0                                                   # an utterance without labels
+    lp = np_log_softmax32(logits)
+    ref = oracle.rnnt_loss_f32(lp, labels, xn, yn, blank=0, fastemit_lambda=lam, scan_mode=1)
+    xs, ys = pack(lp, labels, xn, yn)
+    costs, grads, loc, _ = _ref_compact_abi(xs, ys, xn, yn, 0, lam)
+    assert warp_rnnt_amd.last_lattice_kernel() == kernel
+    np.testing.assert_allclose(costs.cpu().numpy(), ref["costs"], rtol=1e-5)
+    g2 = np.concatenate([oracle.gather_f32(ref["grads"][n:n + 1, :xn[n], :yn[n] + 1], labels[n:n + 1, :yn[n]], 0)[0]
+                         .reshape(-1, 2) for n in range(N)])
+    lastcol = np.concatenate([np.tile(np.arange(yn[n] + 1) == yn[n], xn[n]) for n in range(N)])
+    g2[lastcol, 1] = 0
+    np.testing.assert_allclose(grads.cpu().numpy(), g2, atol=5e-4)
+    with warp_rnnt_amd.lattice_route("logdomain"):
+        c_nat, g_nat, loc_nat = core.rnnt_loss_compact(T(xs), T(ys), T(xn), T(yn), blank=0, fastemit_lambda=lam)
+    assert torch.equal(c_nat, costs) and torch.equal(g_nat, grads) and torch.equal(loc_nat, loc)
+    # costs-only mode (alphas and grads alias betas: the direct form)
+    c2, _, _, _ = _ref_compact_abi(xs, ys, xn, yn, 0, lam, required_grad=False)
+    np.testing.assert_allclose(c2.cpu().numpy(), ref["costs"], rtol=1e-5)
+
+
 @pytest.mark.parametrize("route", ["logdomain", "pd", "auto"])
 @pytest.mark.parametrize("N,Tm,Um,V,lam", [
     (3, 40, 12, 9, 0.0),          # one column block

@@ -587,3 +587,131 @@ def test_padded_labels_may_hold_any_sentinel(V, pad):
     for n in range(N):
         np.testing.assert_array_equal(out[n, :, :yn[n] + 1, 0], good[n, :, :yn[n] + 1, 0])
         np.testing.assert_array_equal(out[n, :, :yn[n], 1], good[n, :, :yn[n], 1])
+
+
+# ----------------------------------------------------------------------------
+# 9. masked log-probs (-inf) -- the rim of the lattice is plain sums in the reference (core_gather.cu:76-104, 177-205:
+#    a -inf there stays -inf and the lattice behind it stays finite), the interior is log_sum_exp (core_gather.cu:22-35:
+#    lse(-inf, -inf) = NaN).  Same NaN pattern, same zeros, same finite values as the oracle, on every route.
+# ----------------------------------------------------------------------------
+def _masked_case(N, T, U, V, seed):
+    """Ragged batch with -inf planted: utterance 0 a masked label in row 0 (alpha's rim) and one in the last row (beta's),
+    utterance 1 a masked blank in column 0 and one in the last column, utterance 2 a whole masked frame (every path
+    crosses it: NaN), utterance 3 interior cells only, the rest untouched."""
+    logits, labels, xn, yn = make_case(seed, N, T, U, V, ragged=True)
+    lp = np_log_softmax32(logits)
+    lab = lambda n, u: labels[n, u]                               # noqa: E731
+    lp[0, 0, 1, lab(0, 1)] = -np.inf
+    lp[0, xn[0] - 1, min(2, yn[0] - 1), lab(0, min(2, yn[0] - 1))] = -np.inf
+    lp[1, min(2, xn[1] - 2), 0, 0] = -np.inf
+    lp[1, xn[1] // 2, yn[1], 0] = -np.inf
+    lp[2, xn[2] // 2, :, :] = -np.inf
+    lp[3, xn[3] // 3, yn[3] // 2, lab(3, yn[3] // 2)] = -np.inf
+    lp[3, xn[3] // 2, yn[3] // 3, 0] = -np.inf
+    return lp, labels, xn, yn
+
+
+def _same_pattern(got_c, got_g, ref, atol, what):
+    rc, rg = ref["costs"], ref["grads"]
+    np.testing.assert_array_equal(np.isnan(got_c), np.isnan(rc), err_msg=what + ": NaN costs")
+    np.testing.assert_array_equal(np.isnan(got_g), np.isnan(rg), err_msg=what + ": NaN gradients")
+    ok = ~np.isnan(rc)
+    np.testing.assert_allclose(got_c[ok], rc[ok], rtol=COST_RTOL, err_msg=what)
+    okg = ~np.isnan(rg)
+    np.testing.assert_allclose(got_g[okg], rg[okg], atol=atol, err_msg=what)
+    np.testing.assert_array_equal((got_g == 0) & okg, (rg == 0) & okg, err_msg=what + ": zero gradients")
+
+
+@pytest.mark.parametrize("N,T,U,V", [(5, 9, 6, 5), (5, 70, 40, 6), (5, 260, 150, 5), (6, 80, 330, 4)])
+def test_masked_log_probs_nan_pattern_equals_the_oracles(N, T, U, V):
+    import warp_rnnt
+    import warp_rnnt_amd
+    np.seterr(all="ignore")
+    lp, labels, xn, yn = _masked_case(N, T, U, V, 4242 + T)
+    ref = oracle.rnnt_loss_f32(lp, labels, xn, yn, blank=0, scan_mode=1)
+    assert np.isnan(ref["costs"][2]) and np.isfinite(ref["costs"][[0, 1, 3]]).all()     # what the reference does
+    lp2 = oracle.gather_f32(lp, labels, 0)
+    ref2 = oracle.rnnt_loss_f32(lp2, labels, xn, yn, blank=-1, scan_mode=1)
+    atol = 1e-4 if T + U <= 250 else 5e-4
+    # native op, dense and gathered layouts, under every kernel of the log-domain route and under the pd route (whose
+    # input check hands masked utterances to the log-domain kernel)
+    for kern in ("auto", "ws", "wd", "wl"):
+        old = warp_rnnt_amd.set_logdomain_kernel(kern)
+        try:
+            c, g = run_native(lp, labels, xn, yn, blank=0)
+            _same_pattern(c, g, ref, atol, f"dense, kernel {kern}")
+            c2, g2 = run_native(lp2, labels, xn, yn, blank=-1)
+            _same_pattern(c2, g2, ref2, atol, f"gathered, kernel {kern}")
+        finally:
+            warp_rnnt_amd.set_logdomain_kernel(old)
+    with warp_rnnt_amd.lattice_route("pd"):
+        c2, g2 = run_native(lp2, labels, xn, yn, blank=-1)
+    _same_pattern(c2, g2, ref2, atol, "gathered, pd route")
+    # reference C ABI, both layouts
+    ca, ga = _call_ref_abi(lp, labels, xn, yn, 0, 0.0)
+    _same_pattern(ca, ga, ref, atol, "run_warp_rnnt")
+    cb, gb = _call_ref_abi(lp2, labels, xn, yn, -1, 0.0)
+    _same_pattern(cb, gb, ref2, atol, "run_warp_rnnt_gather")
+    # the wrapper, gather=True: dense gradients through the gather's backward
+    x = t32(lp).requires_grad_(True)
+    costs = warp_rnnt.rnnt_loss(x, t32(labels), t32(xn), t32(yn), gather=True)
+    costs.sum().backward()
+    _same_pattern(costs.detach().cpu().numpy(), x.grad.cpu().numpy(), ref, atol, "rnnt_loss(gather=True)")
+    # compact layout
+    V_ = lp.shape[-1]
+    rows = np.concatenate([lp[n, :xn[n], :yn[n] + 1].reshape(-1, V_) for n in range(N)])
+    labs = np.concatenate([labels[n, :yn[n]] for n in range(N)]).astype(np.int32)
+    xr = t32(np.ascontiguousarray(rows)).requires_grad_(True)
+    cc = warp_rnnt.rnnt_loss(xr, t32(labs), t32(xn), t32(yn), compact=True)
+    cc.sum().backward()
+    want = np.concatenate([ref["grads"][n, :xn[n], :yn[n] + 1].reshape(-1, V_) for n in range(N)])
+    _same_pattern(cc.detach().cpu().numpy(), xr.grad.cpu().numpy(), {"costs": ref["costs"], "grads": want}, atol,
+                  "rnnt_loss(compact=True)")
+
+
+def test_the_reference_named_entry_points_give_one_utterance_the_same_bits_in_any_batch():
+    """csrc/api.hip: run_warp_rnnt / run_warp_rnnt_gather take the staged forms from 2^20 cells on and the direct ones
+    below -- different kernels (the tuned column-block kernels on a staged plane / the single-role kernel on the
+    caller's layout), one arithmetic: an utterance's costs and gradients do not depend on the batch it came in."""
+    T, U, V, lam = 300, 200, 5, 0.01
+    logits, labels, xn, yn = make_case(77, 2, T, U, V, ragged=True)
+    lp = np_log_softmax32(logits)
+    reps = 9                                                         # 18 x 300 x 200 = 1.08 M cells: staged
+    assert 2 * T * U < (1 << 20) <= 2 * reps * T * U
+    big = lambda a: np.concatenate([a] * reps)                       # noqa: E731
+    for blank, x in ((0, lp), (-1, oracle.gather_f32(lp, labels, 0))):
+        c_small, g_small = _call_ref_abi(x, labels, xn, yn, blank, lam)
+        c_big, g_big = _call_ref_abi(big(x), big(labels), big(xn), big(yn), blank, lam)
+        np.testing.assert_array_equal(c_big[:2], c_small)
+        np.testing.assert_array_equal(c_big[-2:], c_small)
+        np.testing.assert_array_equal(g_big[:2], g_small)
+        np.testing.assert_array_equal(g_big[-2:], g_small)
+
+
+def test_lattice_route_per_call():
+    """ops.loss(..., lattice=) / rnnt_amd_loss_ex: the route of ONE call, whatever the process-wide setting says, and
+    without touching it."""
+    import warp_rnnt_amd
+    from warp_rnnt_amd import ops
+    N, T, U, V = 3, 700, 70, 6                                      # long enough for the probability domain to differ
+    logits, labels, xn, yn = make_case(5, N, T, U, V, ragged=True)
+    lp2 = t32(oracle.gather_f32(np_log_softmax32(logits), labels, 0))
+    txn, tyn = t32(xn), t32(yn)
+    run = lambda **kw: ops.loss(lp2, None, txn, tyn, ops.IN_LOG_PROBS_GATHERED, ops.GRADS_GATHERED, **kw)   # noqa: E731
+    assert warp_rnnt_amd.get_lattice() == "auto"
+    c_def, g_def = run()
+    c_log, g_log = run(lattice="logdomain")
+    c_pd, g_pd = run(lattice="pd")
+    assert warp_rnnt_amd.last_lattice_kernel() == "lattice_pd" and warp_rnnt_amd.get_lattice() == "auto"
+    assert torch.equal(c_def, c_log) and torch.equal(g_def, g_log)
+    assert not torch.equal(g_pd, g_log)                             # another arithmetic ...
+    np.testing.assert_allclose(g_pd.cpu().numpy(), g_log.cpu().numpy(), atol=2e-3)   # ... of the same quantity
+    with warp_rnnt_amd.lattice_route("pd"):                         # the process-wide default is only a default
+        c, g = run(lattice="logdomain")
+        assert torch.equal(c, c_log) and torch.equal(g, g_log)
+        c, g = run()
+        assert torch.equal(g, g_pd)
+    with pytest.raises(ValueError, match="unknown lattice route"):
+        run(lattice="exact")
+    L = warp_rnnt_amd.load()
+    assert L.rnnt_amd_loss_ex(None, None, 0, None, None, None, None, None, None, 0, 1, 1, 1, 1, 0, 0.0, 7) == 5

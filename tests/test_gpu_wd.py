@@ -1,5 +1,8 @@
 """The distributed log-domain lattice kernel (csrc/lattice_wd.hip: one workgroup per 64-column block, boundary
-columns through L2 rings) against the single-workgroup one (csrc/lattice_ws.hip) and the oracle.
+columns through L2 rings) and its single-workgroup form (k_lattice_wl: boundary columns through LDS) against the older
+single-workgroup kernel (csrc/lattice_ws.hip) and the oracle.  The steady-state blocks of the first two are hand-written
+assembly since round 5 (csrc/lattice_step.h), the predicated blocks and all of lattice_ws.hip are C++ with the same
+operations in the same order: these tests are what holds the two implementations of the step to the same bits.
 
 Both kernels call the same step function (csrc/lattice_step.h), so they must agree BIT FOR BIT on costs and gradients
 whatever the shape, the batch size, the layout and the timing of the hand-overs -- that is what makes the kernel choice a
@@ -60,6 +63,13 @@ def test_same_bits_as_the_single_workgroup_kernel(N, T, U, ragged):
     c_wd, g_wd = _run(lp2, txn, tyn, "wd", lam=0.01)
     assert torch.equal(c_ws, c_wd)
     assert torch.equal(g_ws, g_wd)
+    # its single-workgroup form (k_lattice_wl: three waves per column block, boundary columns through LDS; "wl" lets it
+    # take every lattice its LDS holds: U <= 320, 148 KiB -- beyond that the call falls through to lattice_ws.hip)
+    c_wl, g_wl = _run(lp2, txn, tyn, "wl", lam=0.01)
+    if 64 < U <= 320:
+        assert warp_rnnt_amd.last_lattice_kernel() == "lattice_wl"
+    assert torch.equal(c_ws, c_wl)
+    assert torch.equal(g_ws, g_wl)
     if N * T * U <= 400_000:
         o = oracle.rnnt_loss_f32(lp2.cpu().numpy(), None, xn, yn, blank=-1, fastemit_lambda=0.01)
         # (two fp32 implementations of one operation order: 1e-4 up to T+U ~ 200, the rounding of |alpha| beyond)
@@ -175,7 +185,7 @@ def test_compact_layout_same_bits(N, T, U, V):
     rows = torch.cat([lp[n, :xn[n], :yn[n] + 1].reshape(-1, V) for n in range(N)]).contiguous()
     labs = torch.cat([tl[n, :yn[n]] for n in range(N)]).contiguous()
     out = {}
-    for k in ("ws", "wd"):
+    for k in ("ws", "wd", "wl"):
         old_r = warp_rnnt_amd.set_lattice("logdomain")
         old_k = warp_rnnt_amd.set_logdomain_kernel(k)
         try:
@@ -188,3 +198,4 @@ def test_compact_layout_same_bits(N, T, U, V):
             warp_rnnt_amd.set_lattice(old_r)
             warp_rnnt_amd.set_logdomain_kernel(old_k)
     assert torch.equal(out["ws"][0], out["wd"][0]) and torch.equal(out["ws"][1], out["wd"][1])
+    assert torch.equal(out["ws"][0], out["wl"][0]) and torch.equal(out["ws"][1], out["wl"][1])

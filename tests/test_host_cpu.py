@@ -412,3 +412,24 @@ def test_committed_traffic_file_has_what_bench_reads():
         assert rec["source"] and rec["kernel"], key
         assert 0.9 * alg < rec["traffic_bytes"] < 2.0 * alg, (key, rec["traffic_bytes"])
 
+
+
+def test_in_place_reloads_of_the_lattice_kernels_are_not_touched_before_their_wait():
+    """tools/check_inplace_reloads.py on the ISA hipcc generates for csrc/lattice_wd.hip: between an in-place LDS reload of
+    a block's pairs / seeds (inline assembly the compiler does not count) and the `s_waitcnt lgkmcnt(0)` in front of the
+    block barrier, nothing -- in particular nothing the compiler added: a copy at a loop head, a temporary -- reads or
+    writes the registers being refilled.  And the checker itself notices when something does."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import check_inplace_reloads as chk
+    path = chk.compile_to_asm(os.path.join(ROOT, "warp_rnnt_amd", "csrc", "lattice_wd.hip"))
+    kernels, reloads, bad = chk.check(path)
+    assert kernels >= 4 and reloads >= 200, (kernels, reloads)      # (wd + wl, padded + compact; 24 per fast block at least)
+    assert not bad, bad[:5]
+    text = open(path).read()
+    m = re.search(r"(ds_read2st64_b64 v\[(\d+):\d+\], v\d+ offset0:0 offset1:1\n\t;;#ASMEND\n)", text)
+    assert m
+    broken = text.replace(m.group(1), m.group(1) + "\tv_mov_b32_e32 v255, v%s\n" % m.group(2), 1)
+    bpath = path + ".broken.s"
+    with open(bpath, "w") as f:
+        f.write(broken)
+    assert len(chk.check(bpath)[2]) == 1

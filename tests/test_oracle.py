@@ -138,3 +138,32 @@ def test_mismatch_guard_silent_on_consistent_input():
 def test_log_softmax_oracle():
     x = np.random.RandomState(0).randn(37, 50).astype(np.float32) * 3
     np.testing.assert_allclose(oracle.log_softmax_f32(x), transduce_np.log_softmax(x), atol=2e-6)
+
+
+def test_masked_log_probs_follow_the_reference_rim_and_interior_rules():
+    """What the reference does with -inf log-probs, restated: the rim of the lattice is plain sums (core_gather.cu:76-104,
+    177-205), so a masked label in row 0 / the last row, or a masked blank in column 0 / the last column, leaves -inf
+    there and a FINITE cost (the other paths carry it); the interior is log_sum_exp (core_gather.cu:22-35), where two
+    -inf operands give -inf - -inf = NaN, so a frame nobody can cross gives a NaN cost.  The GPU tests hold the HIP
+    kernels to this pattern (tests/test_gpu_parity.py)."""
+    np.seterr(all="ignore")
+    rng = np.random.RandomState(3)
+    N, T, U = 3, 7, 5
+    lp2 = np_log_softmax32(rng.randn(N, T, U, 2))
+    labels = np.ones((N, U - 1), dtype=np.int32)
+    xn, yn = np.full((N,), T, np.int32), np.full((N,), U - 1, np.int32)
+    clean = oracle.rnnt_loss_f32(lp2, labels, xn, yn, blank=-1, scan_mode=1)
+    lp2[0, 0, 1, 1] = -np.inf            # rim: label out of (0,1)
+    lp2[0, T - 1, 2, 1] = -np.inf        # rim: label out of (T-1,2)
+    lp2[1, 2, 0, 0] = -np.inf            # rim: blank out of (2,0)
+    lp2[1, 3, U - 1, 0] = -np.inf        # rim: blank out of (3,U-1)
+    lp2[2, 3] = -np.inf                  # a frame without an exit
+    for scan_mode in (0, 1):
+        r = oracle.rnnt_loss_f32(lp2, labels, xn, yn, blank=-1, scan_mode=scan_mode)
+        assert np.isfinite(r["costs"][:2]).all() and np.isnan(r["costs"][2])
+        assert (r["costs"][:2] > clean["costs"][:2]).all()            # paths were removed, none added
+        assert not np.isnan(r["grads"][:2]).any()
+        assert np.isneginf(r["alphas"][0, 0, 2:]).all() and np.isfinite(r["alphas"][0, 1:, 2:]).all()
+        assert np.isneginf(r["alphas"][1, 3:, 0]).all() and np.isfinite(r["alphas"][1, 3:, 1:]).all()
+        assert r["grads"][0, 0, 1, 1] == 0 and r["grads"][1, 2, 0, 0] == 0   # exp(-inf): no gradient through a masked arc
+        assert np.isnan(r["alphas"][2, 4, 1:]).all() and np.isneginf(r["alphas"][2, 4, 0])

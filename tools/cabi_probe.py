@@ -6,6 +6,9 @@ straight into libwarp_rnnt_amd.so -- next to the native workspace entry on the s
 
     python tools/cabi_probe.py [c2 c4 ...]           (shapes of bench.py's configs; default c2 c4)
 
+and the three compact entry points (run_gather_for_compact, run_warp_rnnt_compact, run_scatter_grad_for_compact) in the
+sequence of binding.cpp:139-204 / 209-247 on a ragged batch of the same shape, next to the native compact entries.
+
 ms per call, HIP events around `reps` back-to-back calls; "alloc+call" includes the binding's allocations and the
 zero-fills the C contract asks for, "call" is the entry point alone on buffers zeroed outside the timed region."""
 import os
@@ -64,6 +67,108 @@ def time_entries(lp, ys, xn, yn, reps=5):
     return {"cabi_gather_ms": round(timed(gather_call, reps), 4), "cabi_dense_ms": round(timed(dense_call, reps), 4),
             "cabi_note": "run_warp_rnnt_gather / run_warp_rnnt through ctypes with the reference binding's own "
                          "allocations and zero-fills (binding.cpp:58-99), tools/cabi_probe.py"}
+
+
+def ragged_compact_batch(N, T, U, V, dev, seed=11):
+    """A ragged batch in the reference's compact packing (benchmark.py:20-24's length rule: frames in [T/2, T], labels in
+    [U/2, U-1], shifted so that the maxima are T and U-1): xs (STU,V) log-probs, ys (sum yn,), xn, yn."""
+    g = torch.Generator(device="cpu")
+    g.manual_seed(seed)
+    xn = torch.randint(T // 2, T + 1, (N,), generator=g, dtype=torch.int32)
+    yn = torch.randint(U // 2, U, (N,), generator=g, dtype=torch.int32)
+    xn = (xn + (T - xn.max())).to(torch.int32)
+    yn = (yn + (U - 1 - yn.max())).to(torch.int32)
+    STU = int((xn.long() * (yn.long() + 1)).sum())
+    gd = torch.Generator(device=dev)
+    gd.manual_seed(seed)
+    xs = torch.log_softmax(torch.randn((STU, V), device=dev, generator=gd), -1)
+    ys = torch.randint(1, V, (int(yn.sum()),), dtype=torch.int32, device=dev, generator=gd)
+    return xs, ys, xn.to(dev), yn.to(dev)
+
+
+def time_compact_entries(xs, ys, xn, yn, reps=5, backward=True):
+    """ms per call of the reference binding's compact sequence on the reference-named entry points (binding.cpp:139-204,
+    209-247: exclusive prefix sums with torch ops, run_gather_for_compact, run_warp_rnnt_compact, and -- backward --
+    run_scatter_grad_for_compact into zeros), its allocations included, NULL stream as there; next to the native entries
+    on the same tensors (rnnt_amd_compact_offsets + rnnt_amd_loss_compact [+ rnnt_amd_compact_scatter_grads] through
+    warp_rnnt_amd.ops, one read-back).  The reference's four host read-backs (yn.sum, xn.max, yn.max, the last prefix) are
+    kept in the timed sequence: they are part of what its binding does per call."""
+    L = _lib.load()
+    dev = xs.device
+    N, V = xn.shape[0], xs.shape[1]
+    out = {}
+
+    def shim_call():
+        n_labels = int(yn.sum().item())
+        Tm, Um = int(xn.max().item()), int(yn.max().item()) + 1
+        mem = (xn * (yn + 1)).cumsum(0, dtype=torch.int32)
+        lab = yn.cumsum(0, dtype=torch.int32)
+        STU = int(mem[-1].item())
+        assert STU == xs.shape[0] and n_labels == ys.numel()
+        mem_pref = torch.cat([mem.new_zeros(1), mem[:-1]]).contiguous()
+        lab_pref = torch.cat([lab.new_zeros(1), lab[:-1]]).contiguous()
+        gather_xs = torch.empty((STU, 2), device=dev)
+        loc = torch.zeros((STU,), dtype=torch.int64, device=dev)
+        L.run_gather_for_compact(xs.data_ptr(), ys.data_ptr(), xn.data_ptr(), yn.data_ptr(), gather_xs.data_ptr(),
+                                 loc.data_ptr(), mem_pref.data_ptr(), lab_pref.data_ptr(), N, Tm, Um, V, 0)
+        costs = torch.empty((N,), device=dev)
+        counts = torch.zeros((n_labels * 2 + 2 * N,), dtype=torch.int32, device=dev)
+        betas = torch.empty((STU,), device=dev)
+        alphas, grads = torch.empty_like(betas), torch.empty_like(gather_xs)
+        L.run_warp_rnnt_compact(counts.data_ptr(), alphas.data_ptr(), betas.data_ptr(), gather_xs.data_ptr(),
+                                grads.data_ptr(), costs.data_ptr(), xn.data_ptr(), yn.data_ptr(), mem_pref.data_ptr(),
+                                lab_pref.data_ptr(), N, Tm, Um, 0.0, True)
+        shim_call.res = (costs, grads, loc, mem)
+        return costs, grads, loc, mem
+
+    ones = torch.ones((N,), device=dev)
+
+    def shim_train():
+        costs, grads, loc, cum = shim_call()
+        dense = torch.zeros((xs.shape[0], V), device=dev)
+        L.run_scatter_grad_for_compact(ones.data_ptr(), grads.data_ptr(), loc.data_ptr(), cum.data_ptr(), dense.data_ptr(),
+                                       xs.shape[0], N, V, 0)
+
+    def native_call():
+        native_call.res = ops.loss_compact(xs, ys, xn, yn)
+        return native_call.res
+
+    def native_train():
+        costs, grads, loc = native_call()
+        cum = (xn * (yn + 1)).cumsum(0, dtype=torch.int32)
+        ops.compact_scatter_grads(ones, grads, cum, loc, V, 0)
+
+    # The shims work on the NULL stream, torch on its own (blocking) stream: the two serialise against each other, and the
+    # events of timed() are recorded on torch's stream, so they bracket the NULL-stream work as well.
+    out["cabi_compact_ms"] = round(timed(shim_call, reps), 4)
+    out["native_compact_ms"] = round(timed(native_call, reps), 4)
+    if backward:
+        out["cabi_compact_train_ms"] = round(timed(shim_train, reps), 4)
+        out["native_compact_train_ms"] = round(timed(native_train, reps), 4)
+    torch.cuda.synchronize()
+    assert L.rnnt_amd_compact_last_status() == 0
+    c_shim, c_nat = shim_call.res[0], native_call.res[0]
+    out["cabi_compact_vs_native_max_rel_cost"] = float((c_shim / c_nat - 1).abs().max())
+    out["cabi_compact_note"] = ("binding.cpp:139-204's sequence on run_gather_for_compact + run_warp_rnnt_compact "
+                                "(+ run_scatter_grad_for_compact: *_train_ms) with its allocations and four read-backs, "
+                                "next to ops.loss_compact (+ ops.compact_scatter_grads) on the same ragged batch, "
+                                "tools/cabi_probe.py")
+    return out
+
+
+def probe_compact(name):
+    N, T, U, V = SHAPES[name]
+    dev = torch.device("cuda:0")
+    xs, ys, xn, yn = ragged_compact_batch(N, T, U, V, dev)
+    reps = 20 if N * T * U * V < 10 ** 8 else 5
+    r = time_compact_entries(xs, ys, xn, yn, reps)
+    print(f"{name} ragged, compact packing: N={N} T<={T} U<={U} V={V}, {xs.shape[0]} of {N * T * U} cells "
+          f"(costs shim vs native: max rel {r['cabi_compact_vs_native_max_rel_cost']:.1e})")
+    for k in ("cabi_compact_ms", "native_compact_ms", "cabi_compact_train_ms", "native_compact_train_ms"):
+        print(f"    {k:58s} {r[k]:8.4f} ms")
+    print(f"    shim / native: forward {r['cabi_compact_ms'] / r['native_compact_ms']:.2f}x, "
+          f"forward + scatter {r['cabi_compact_train_ms'] / r['native_compact_train_ms']:.2f}x")
+    return r
 
 
 def probe(name):
@@ -140,3 +245,4 @@ def probe(name):
 if __name__ == "__main__":
     for nm in (sys.argv[1:] or ["c2", "c4"]):
         probe(nm)
+        probe_compact(nm)

@@ -2,11 +2,13 @@
 """Times the alpha+beta sweeps alone under every route of the in-tree library, in one process, for a list of shapes:
 
     pd   probability domain, one workgroup per column block            (csrc/lattice_pd.hip)
-    ws   log domain, one workgroup per sweep                           (csrc/lattice_ws.hip; U <= 512)
+    ws   log domain, one workgroup per sweep, compute + I/O wave pairs (csrc/lattice_ws.hip; U <= 512)
     wd   log domain, one workgroup per column block ("distributed")    (csrc/lattice_wd.hip)
+    wl   log domain, one workgroup per sweep, wd's three wave roles    (csrc/lattice_wd.hip: k_lattice_wl; 64 < U <= 320)
+    auto what launch_lattice picks by shape
 
-and checks that ws and wd leave the same bits in the alpha / beta planes (full-length utterances, so every cell is
-live).  HIP events around 5 back-to-back launches, 10 rounds, median / min in us.
+and checks that ws, wd, wl and auto leave the same bits in the alpha / beta planes (full-length utterances, so every cell
+is live).  WARP_RNNT_AMD_LIB=<variant .so> times another build of the library (e.g. the wd_k16 variant).  HIP events around 5 back-to-back launches, 10 rounds, median / min in us.
 
     python tools/lattice_routes.py [N,T,U ...]
 """
@@ -22,8 +24,8 @@ import warp_rnnt_amd  # noqa: E402
 from warp_rnnt_amd import _lib  # noqa: E402
 
 DEFAULT = ["16,1500,64", "16,1500,128", "16,1500,300", "16,1500,512", "8,3000,500", "24,1500,300", "32,1500,300",
-           "64,1500,300", "128,1500,300", "16,700,100", "16,400,100", "16,150,40", "32,150,20", "64,500,100",
-           "32,1000,200", "16,1500,600"]
+           "64,1500,300", "128,1500,300", "16,700,100", "16,400,100", "32,250,100", "16,150,40", "32,150,20", "64,500,100",
+           "32,1000,200", "32,500,200", "64,300,128", "16,1500,600"]
 
 
 def run(shape, L, dev):
@@ -41,10 +43,13 @@ def run(shape, L, dev):
     plane = (cells * 4 + 255) // 256 * 256
     row = {}
     planes = {}
-    for name, route, kern in (("pd", "pd", "auto"), ("ws", "logdomain", "ws"), ("wd", "logdomain", "wd")):
+    for name, route, kern in (("pd", "pd", "auto"), ("ws", "logdomain", "ws"), ("wd", "logdomain", "wd"),
+                              ("wl", "logdomain", "wl"), ("auto", "auto", "auto")):
         if name == "ws" and U > 512:
             continue
-        if name == "pd" and U > 512:
+        if name == "pd" and (U > 512 or os.environ.get("ROUTES_NO_PD")):
+            continue
+        if name == "wl" and not 64 < U <= 320:
             continue
         warp_rnnt_amd.set_lattice(route)
         warp_rnnt_amd.set_logdomain_kernel(kern)
@@ -54,7 +59,7 @@ def run(shape, L, dev):
         assert st == 0, st
         torch.cuda.synchronize()
         planes[name] = (ws[:cells * 4].view(torch.float32).clone(), ws[plane:plane + cells * 4].view(torch.float32).clone(),
-                        float(costs.double().sum().item()))
+                        float(costs.double().sum().item()), warp_rnnt_amd.last_lattice_kernel())
         times = []
         for rnd in range(12):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -66,13 +71,15 @@ def run(shape, L, dev):
             if rnd >= 2:
                 times.append(e0.elapsed_time(e1) * 1000 / 5)
         row[name] = (statistics.median(times), min(times))
-    same = "-"
-    if "ws" in planes and "wd" in planes:
-        same = "same bits" if (torch.equal(planes["ws"][0], planes["wd"][0]) and
-                               torch.equal(planes["ws"][1], planes["wd"][1])) else "DIFFERENT"
+    base = "ws" if "ws" in planes else "wd"
+    same = []
+    for k in ("wd", "wl", "auto"):
+        if k in planes and k != base:
+            ok = torch.equal(planes[base][0], planes[k][0]) and torch.equal(planes[base][1], planes[k][1])
+            same.append(f"{k} {'=' if ok else 'DIFFERS FROM'} {base}")
     cells_txt = " ".join(f"{k} {row[k][0]:7.1f} ({row[k][1]:6.1f})" if k in row else f"{k}       -         "
-                         for k in ("pd", "ws", "wd"))
-    print(f"N={N:4d} T={T:5d} U={U:4d}   {cells_txt}   ws/wd: {same}   sum(costs) wd {planes['wd'][2]:.4f}", flush=True)
+                         for k in ("pd", "ws", "wd", "wl", "auto"))
+    print(f"N={N:4d} T={T:5d} U={U:4d}   {cells_txt}   [{', '.join(same)}; auto -> {planes['auto'][3]}]", flush=True)
     warp_rnnt_amd.set_lattice("auto")
     warp_rnnt_amd.set_logdomain_kernel("auto")
 

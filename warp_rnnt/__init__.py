@@ -139,9 +139,15 @@ def rnnt_loss(log_probs: torch.FloatTensor,
     ``max_frames``, ``max_labels``  (not in the reference; compact only) upper bounds of ``frames_lengths`` /
                         ``labels_lengths`` the caller vouches for.  With them the compact path reads nothing back
                         from the device -- no host synchronisation (the reference's has four, this one otherwise one)
-                        and the call can be captured into a HIP graph; a batch that does not fit them gives NaN costs.
+                        and the call can be captured into a HIP graph.  In exchange the shape errors the reference raises
+                        from the host (a length above the bound, ``labels`` / ``log_probs`` sizes that are not the sums of
+                        the lengths) cannot be raised: such a batch is refused on the device and comes back with NaN costs
+                        and zero gradients -- which ``reduction='mean'`` turns into a NaN loss.  Passing them without
+                        ``compact=True`` is an error (``ValueError``): the padded layouts need no bounds.
     """
     _check_call(average_frames, reduction, blank, gather, labels, frames_lengths, labels_lengths)
+    if not compact and (max_frames is not None or max_labels is not None):
+        raise ValueError("max_frames / max_labels are launch bounds of the compact layout: pass compact=True with them")
 
     if compact:
         wants_grad = log_probs.requires_grad and torch.is_grad_enabled()

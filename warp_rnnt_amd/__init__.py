@@ -23,8 +23,9 @@ def set_lattice(route):
     ``rnnt_amd_set_lattice``): ``"auto"`` (default) and ``"logdomain"`` are the reference's fp32 log-sum-exp per cell
     -- the same bits whatever the batch an utterance is computed in; ``"pd"`` is the probability-domain kernel wherever
     it is supported (padded or compact layout, U <= 512): closer to exact arithmetic on long lattices (7e-4 instead of
-    1e-2 on the gradients at T=1500, U=300), not the reference's numbers.  Process-wide and not thread-safe: callers on
-    several threads that want different routes must serialise.  Returns the previous route."""
+    1e-2 on the gradients at T=1500, U=300), not the reference's numbers.  Process-wide: the DEFAULT of every call that
+    does not name its own route -- ``warp_rnnt_amd.ops.loss(..., lattice="pd")`` / ``ops.loss_compact(..., lattice=)``
+    choose per call and touch no state, which is what callers on several threads want.  Returns the previous route."""
     if route not in LATTICE_ROUTES:
         raise ValueError(f"unknown lattice route {route!r}: expected one of {LATTICE_ROUTES}")
     return LATTICE_ROUTES[load().rnnt_amd_set_lattice(LATTICE_ROUTES.index(route))]
@@ -44,19 +45,20 @@ def lattice_route(route):
     finally:
         set_lattice(old)
 
-LOGDOMAIN_KERNELS = ("auto", "ws", "wd")
+LOGDOMAIN_KERNELS = ("auto", "ws", "wd", "wl")
 
 
 def set_logdomain_kernel(kernel):
     """Which kernel serves the log-domain arithmetic (``rnnt_amd_set_logdomain_kernel``): ``"auto"`` by shape, ``"ws"``
-    one workgroup per sweep, ``"wd"`` one workgroup per 64-column block.  Same bits either way: a tuning / test knob.
+    one workgroup per sweep, ``"wd"`` one workgroup per 64-column block, ``"wl"`` the single-workgroup form of ``wd``
+    wherever it fits.  Same bits whichever runs: a tuning / test knob.
     Process-wide, not thread-safe (like :func:`set_lattice`).  Returns the previous setting."""
     if kernel not in LOGDOMAIN_KERNELS:
         raise ValueError(f"unknown log-domain kernel {kernel!r}: expected one of {LOGDOMAIN_KERNELS}")
     return LOGDOMAIN_KERNELS[load().rnnt_amd_set_logdomain_kernel(LOGDOMAIN_KERNELS.index(kernel))]
 
 
-LATTICE_KERNELS = ("none", "lattice_ws", "lattice_wd", "lattice_pd", "lattice (single role)")
+LATTICE_KERNELS = ("none", "lattice_ws", "lattice_wd", "lattice_pd", "lattice (single role)", "lattice_wl")
 
 
 def last_lattice_kernel():

@@ -58,6 +58,8 @@ VARIANTS = {
     # hand-over waits that give up at once: every column block that catches up with its neighbour flags its sweep
     # for the log-domain kernel (the "producer lost" path, which never triggers otherwise)
     "short_spin": ["-DRNNT_PD_SPIN_LIMIT=0", "-DRNNT_WD_SPIN_LIMIT=0"],
+    # A/B (tools/lattice_routes.py): blocks of 16 diagonals per barrier in the column-block kernel instead of 8
+    "wd_k16": ["-DRNNT_WD_K=16", "-DRNNT_WL_DEFAULT_MAX_BLOCKS=0"],
 }
 
 

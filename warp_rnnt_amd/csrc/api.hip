@@ -69,7 +69,7 @@ bool dims_ok(int N, int T, int U) {
 
 extern "C" {
 
-int rnnt_amd_version(void) { return 104; }
+int rnnt_amd_version(void) { return 105; }
 
 int rnnt_amd_set_lattice(int route) { return set_lattice_route(route); }
 
@@ -203,6 +203,15 @@ rnntStatus_t rnnt_amd_loss(rnntStream_t stream, void* workspace, int input_kind,
                            const int* labels, const int* xn, const int* yn, float* costs, float* grads,
                            int grads_kind, int N, int T, int U, int V, int blank,
                            float fastemit_lambda) {
+    return rnnt_amd_loss_ex(stream, workspace, input_kind, input, labels, xn, yn, costs, grads, grads_kind, N, T, U, V,
+                            blank, fastemit_lambda, RNNT_LATTICE_DEFAULT);
+}
+
+rnntStatus_t rnnt_amd_loss_ex(rnntStream_t stream, void* workspace, int input_kind, const float* input,
+                              const int* labels, const int* xn, const int* yn, float* costs, float* grads,
+                              int grads_kind, int N, int T, int U, int V, int blank,
+                              float fastemit_lambda, int lattice) {
+    if (lattice != RNNT_LATTICE_DEFAULT && (lattice < ROUTE_AUTO || lattice > ROUTE_PD)) return RNNT_STATUS_INVALID_ARGUMENT;
     if (!dims_ok(N, T, U) || !workspace) return RNNT_STATUS_INVALID_ARGUMENT;
     if (reinterpret_cast<uintptr_t>(workspace) % ALIGN) return RNNT_STATUS_INVALID_ARGUMENT;
     const bool gathered_in = input_kind == RNNT_IN_LOG_PROBS_GATHERED;
@@ -236,7 +245,7 @@ rnntStatus_t rnnt_amd_loss(rnntStream_t stream, void* workspace, int input_kind,
 
     // 2. alpha / beta sweeps (2N workgroups, concurrent)
     LatticeArgs la{w.ws2, nullptr, xn, yn, w.alphas, w.betas, w.ll, T, U, 2, 0, nullptr, w.redo, w.redo + 2 * N, w.mail};
-    la.route = lattice_route();
+    la.route = lattice == RNNT_LATTICE_DEFAULT ? lattice_route() : lattice;
     if (launch_lattice(stream, la, N, LOAD_SKEWED) != hipSuccess) return RNNT_STATUS_WARP_FAILED;
 
     // 3. gradients + costs (+ guard).  For a dense result the pairs are produced in place in the
@@ -348,6 +357,16 @@ rnntStatus_t rnnt_amd_loss_compact(rnntStream_t stream, void* workspace, const f
                                    const int* label_offsets, float* costs, float* grads2, int64_t* loc,
                                    int N, int64_t STU, int Tmax, int Umax, int V, int blank,
                                    float fastemit_lambda) {
+    return rnnt_amd_loss_compact_ex(stream, workspace, xs, ys, xn, yn, cell_offsets, label_offsets, costs, grads2, loc, N,
+                                    STU, Tmax, Umax, V, blank, fastemit_lambda, RNNT_LATTICE_DEFAULT);
+}
+
+rnntStatus_t rnnt_amd_loss_compact_ex(rnntStream_t stream, void* workspace, const float* xs, const int* ys,
+                                      const int* xn, const int* yn, const int64_t* cell_offsets,
+                                      const int* label_offsets, float* costs, float* grads2, int64_t* loc,
+                                      int N, int64_t STU, int Tmax, int Umax, int V, int blank,
+                                      float fastemit_lambda, int lattice) {
+    if (lattice != RNNT_LATTICE_DEFAULT && (lattice < ROUTE_AUTO || lattice > ROUTE_PD)) return RNNT_STATUS_INVALID_ARGUMENT;
     if (!compact_dims_ok(N, STU, Tmax, Umax) || !workspace || V < 1 || blank < 0 || blank >= V)
         return RNNT_STATUS_INVALID_ARGUMENT;
     if (reinterpret_cast<uintptr_t>(workspace) % ALIGN) return RNNT_STATUS_INVALID_ARGUMENT;
@@ -360,7 +379,7 @@ rnntStatus_t rnnt_amd_loss_compact(rnntStream_t stream, void* workspace, const f
                               blank, STU) != hipSuccess)
         return RNNT_STATUS_PROLOGUE_FAILED;
     LatticeArgs la{ws2, nullptr, xn, yn, alphas, betas, ll, Tmax, Umax, 2, 0, cell_offsets, w.redo, w.redo + 2 * N, w.mail};
-    la.route = lattice_route();
+    la.route = lattice == RNNT_LATTICE_DEFAULT ? lattice_route() : lattice;
     if (launch_lattice(stream, la, N, LOAD_SKEWED) != hipSuccess) return RNNT_STATUS_WARP_FAILED;
     GradArgs ga{ws2, nullptr, xn, yn, alphas, betas, ll, grads2 ? grads2 : ws2, costs, mismatch,
                 Tmax, Umax, 2, 0, fastemit_lambda, cell_offsets};
@@ -405,6 +424,13 @@ rnntStatus_t rnnt_amd_loss_compact_bounded(rnntStream_t stream, void* workspace,
         return RNNT_STATUS_INVALID_ARGUMENT;
     if (reinterpret_cast<uintptr_t>(workspace) % ALIGN) return RNNT_STATUS_INVALID_ARGUMENT;
     if (N == 0) return RNNT_STATUS_SUCCESS;
+    if (STU == 0) {
+        // utterances but no cells: no length >= 1 frame can add up to that, so the batch is one this entry always
+        // refuses -- and the kernels behind it return before they write anything.  Say so the way a refusal does.
+        if (hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(costs), 0x7fc00000, (size_t)N, stream) != hipSuccess)
+            return RNNT_STATUS_COSTS_FAILED;
+        return RNNT_STATUS_SUCCESS;
+    }
     BoundedExtra e;
     carve_bounded(static_cast<char*>(workspace), rnnt_amd_workspace_size_compact(N, STU, Tmax, Umax), N, &e);
     const CompactBounds b{e.xn_checked, STU, n_labels, Tmax, Umax};
@@ -489,6 +515,34 @@ void run_warp_rnnt_compact(unsigned int* counts, float* alphas, float* betas, co
     const int* iyn = reinterpret_cast<const int*>(yn);
     // counts (2*sum(yn) + 2N words, binding.cpp:187): the first N hold the alpha-side log-likelihoods
     float* ll = reinterpret_cast<float*>(counts);
+    // Staged like the padded entry points (round 5; until then: the single-role kernel with per-lane row-major loads,
+    // tools/cabi_probe.py): `grads` (STU,2) is the caller's and not yet written -- exactly one plane of pairs.  The
+    // row-major pairs are turned into each utterance's diagonal-major plane there (LDS tiles), the sweeps run on the
+    // tuned kernels that need nothing but planes (k_lattice_wd as a plain launch for U <= 64, k_lattice_wl, lattice_ws.hip),
+    // the gradient pairs replace the log-prob pairs in place, are parked in alphas / betas (dead by then) and turned
+    // back.  Five coalesced passes instead of two whose loads and stores are scattered over the diagonal-major thread
+    // order.  Not for required_grad = false (alphas and grads alias betas there, binding.cpp:192-195) and not below
+    // 2^20 cells of launch bound (launch-bound sizes keep the two-launch form).
+    const bool staged = required_grad && (size_t)N * T * U >= STAGED_FROM_CELLS && reinterpret_cast<uintptr_t>(grads) % 16 == 0 &&
+                        reinterpret_cast<uintptr_t>(alphas) % 8 == 0 && reinterpret_cast<uintptr_t>(betas) % 8 == 0 &&
+                        grads != betas && alphas != betas;
+    if (staged) {
+        hipError_t e = launch_reskew_compact32(nullptr, log_probs, grads, xn, yn, memPref, N, T, U);
+        if (e != hipSuccess) { compact_fail(RNNT_STATUS_PROLOGUE_FAILED, "run_warp_rnnt_compact", costs, N, e); return; }
+        LatticeArgs ls{grads, nullptr, ixn, iyn, alphas, betas, ll, (int)T, (int)U, 2, 0};
+        ls.offs32 = memPref;
+        ls.route = ROUTE_LOGDOMAIN;
+        e = launch_lattice(nullptr, ls, (int)N, LOAD_SKEWED);
+        if (e != hipSuccess) { compact_fail(RNNT_STATUS_WARP_FAILED, "run_warp_rnnt_compact", costs, N, e); return; }
+        GradArgs gs{grads, nullptr, ixn, iyn, alphas, betas, ll, grads, costs, nullptr, (int)T, (int)U, 2, 0, fastemit_lambda};
+        gs.offs32 = memPref;
+        e = launch_grads(nullptr, gs, (int)N, LOAD_SKEWED, WRITE_SKEWED2);
+        if (e != hipSuccess) { compact_fail(RNNT_STATUS_GRADS_BLANK_FAILED, "run_warp_rnnt_compact", costs, N, e); return; }
+        e = launch_split_pairs_compact32(nullptr, grads, alphas, betas, xn, yn, memPref, N, (size_t)N * T * U);
+        if (e == hipSuccess) e = launch_unskew_compact32(nullptr, alphas, betas, grads, xn, yn, memPref, N, T, U);
+        if (e != hipSuccess) compact_fail(RNNT_STATUS_GRADS_LABEL_FAILED, "run_warp_rnnt_compact", costs, N, e);
+        return;
+    }
     LatticeArgs la{log_probs, nullptr, ixn, iyn, alphas, betas, ll, (int)T, (int)U, 2, 0};
     la.offs32 = memPref;
     la.beta_only = required_grad ? 0 : 1;

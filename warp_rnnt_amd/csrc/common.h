@@ -29,6 +29,14 @@ __device__ __forceinline__ float wave_shr1(float first, float src) {
                                            0x138 /* wave_shr:1 */, 0xf, 0xf, false));
 }
 
+// The same shift with lane 0 receiving 0.0 (bound_ctrl: a lane without a source reads zero): no `old` operand, hence no
+// v_mov in front of every shift to seed it.  For the column block that has no left neighbour -- its lane 0 is lattice
+// column 0 (sweep coordinates), whose value never comes out of the lse anyway (boundary_fix in lattice_step.h).
+__device__ __forceinline__ float wave_shr1_z(float src) {
+    return __builtin_bit_cast(
+        float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, src), 0x138 /* wave_shr:1 */, 0xf, 0xf, true));
+}
+
 __device__ __forceinline__ float readlane(float v, int lane) {
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
 }

@@ -80,6 +80,12 @@ size_t pd_mail_bytes(int N, int T, int U);
 // hipErrorNotSupported when they are missing.  Bit-identical to launch_lattice_ws.
 hipError_t launch_lattice_wd(hipStream_t stream, const LatticeArgs& a, int N);
 size_t wd_mail_bytes(int N, int T, int U);
+// ... and its single-workgroup form (lattice_wd.hip: k_lattice_wl): all column blocks of a sweep as waves of one
+// workgroup, boundary columns through LDS; needs nothing but the planes (no flags, no rings), padded or compact with
+// either offset width, honours a.redo and a.beta_only.  hipErrorNotSupported beyond wl_max_blocks() column blocks.
+// Bit-identical to the other two.
+hipError_t launch_lattice_wl(hipStream_t stream, const LatticeArgs& a, int N, int max_blocks);
+int wl_max_blocks();   // what launch_lattice lets it take by itself; set_logdomain_kernel(3) lets it take all it can (5)
 // what a workspace reserves for the hand-over rings of either kernel (a function of the shape only)
 inline size_t lattice_mail_bytes(int N, int T, int U) {
     const size_t p = pd_mail_bytes(N, T, U), w = wd_mail_bytes(N, T, U);
@@ -90,12 +96,12 @@ inline size_t lattice_mail_bytes(int N, int T, int U) {
 // launch counter at flags[n_flags] and zeroes ring_bytes (a multiple of 16) at `rings`.
 hipError_t launch_ring_prepare(hipStream_t stream, int* flags, int n_flags, void* rings, size_t ring_bytes);
 unsigned next_launch_epoch();     // host part of the launch epoch: random start, +1 per call
-// Which kernel serves the log-domain route where both can (same bits either way): 0 = by shape, 1 = single workgroup
-// per sweep (lattice_ws.hip), 2 = one workgroup per column block (lattice_wd.hip).  Initial value from the
-// environment variable RNNT_LOGDOMAIN_KERNEL=ws|wd.
-int last_lattice_kernel();        // what the calling thread's last launch_lattice ran: 1 ws, 2 wd, 3 pd, 4 single-role (0 none yet)
+// Which kernel serves the log-domain route where several can (same bits either way): 0 = by shape, 1 = single workgroup
+// per sweep (lattice_ws.hip), 2 = one workgroup per column block (lattice_wd.hip), 3 = its single-workgroup form
+// (k_lattice_wl) wherever it fits.  Initial value from the environment variable RNNT_LOGDOMAIN_KERNEL=ws|wd|wl.
+int last_lattice_kernel();        // what the calling thread's last launch_lattice ran: 1 ws, 2 wd, 3 pd, 4 single-role, 5 wl (0 none yet)
 int logdomain_kernel();
-int set_logdomain_kernel(int k);  // returns the previous setting, or -1 for an unknown value
+int set_logdomain_kernel(int k);  // 0 by shape, 1 ws, 2 wd, 3 wl (single-workgroup form of wd); returns the previous setting, or -1
 hipError_t launch_grads(hipStream_t stream, const GradArgs& a, int N, int loader, int writer);
 
 // prologue / epilogue streaming kernels
@@ -116,6 +122,15 @@ hipError_t launch_gather_compact_rowmajor(hipStream_t stream, const float* xs, c
                                           const unsigned* yn, float* gather_xs, int64_t* loc, const unsigned* mem_pref,
                                           const unsigned* label_pref, unsigned N, unsigned T, unsigned U, unsigned V,
                                           unsigned blank);
+// the staged form of run_warp_rnnt_compact: row-major packed pairs <-> per-utterance diagonal-major planes, 32-bit prefixes
+hipError_t launch_reskew_compact32(hipStream_t stream, const float* pairs_rowmajor, float* pairs_diagonal,
+                                   const unsigned* xn, const unsigned* yn, const unsigned* mem_pref, unsigned N,
+                                   unsigned Tmax, unsigned Umax);
+hipError_t launch_unskew_compact32(hipStream_t stream, const float* a_diagonal, const float* b_diagonal,
+                                   float* pairs_rowmajor, const unsigned* xn, const unsigned* yn, const unsigned* mem_pref,
+                                   unsigned N, unsigned Tmax, unsigned Umax);
+hipError_t launch_split_pairs_compact32(hipStream_t stream, const float* pairs, float* a, float* b, const unsigned* xn,
+                                        const unsigned* yn, const unsigned* mem_pref, unsigned N, size_t cells_bound);
 hipError_t launch_costs_from_betas(hipStream_t stream, const float* betas, const unsigned* mem_pref, const int* xn,
                                    const int* yn, float* costs, int N);
 // launch bounds and tensor sizes the caller vouches for, checked on the device (rnnt_amd_loss_compact_bounded):

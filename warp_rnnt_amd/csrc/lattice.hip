@@ -101,6 +101,8 @@ __device__ __forceinline__ void run_block(const Cell (&cur)[K], const float mvec
     int soff[K];
 #pragma unroll
     for (int k = 0; k < K; ++k) first[k] = readlane(mvec, k);
+    const int ucol_first = ucol_chk == 0 ? 0x40000001 : ucol_chk;   // the lane's first live diagonal (column 0: none)
+    const bool col0 = ucol_chk == 0;
     const int rowbytes = U * 4;
     const bool nowrap = BETA ? (row_st >= K - 1) : (row_st + K <= T);
     if (nowrap) {
@@ -185,19 +187,24 @@ __device__ __forceinline__ void run_block(const Cell (&cur)[K], const float mvec
         const float l2 = __builtin_amdgcn_logf(u);                                     // chain
         RNNT_PIN();
 #if defined(RNNT_PRECISE_LIBM)
-        const float val = mx + log1pf(expf(-__builtin_fabsf(t)));
+        float val = mx + log1pf(expf(-__builtin_fabsf(t)));
         (void)l2;
 #elif !defined(RNNT_LSE_UNCORRECTED)
         const float c = e - (u - 1.0f);                                                // shadow
         RNNT_PIN();
         const float l = __builtin_fmaf(l2, 0.693147180559945309417f, c);               // chain
         RNNT_PIN();
-        const float val = mx + l;                                                      // chain
+        float val = mx + l;                                                            // chain
 #else
         // Probe only: max + ln2*log2(1+e) in one fma, rounding of 1+e left uncorrected.  4 % faster,
         // but pushes gradients past the 1e-4 parity bar at T=150,U=40 -- not used.
-        const float val = __builtin_fmaf(l2, 0.693147180559945309417f, mx);            // chain
+        float val = __builtin_fmaf(l2, 0.693147180559945309417f, mx);                  // chain
 #endif
+        RNNT_PIN();
+        // the rim of the lattice is plain sums in the reference, not lse (lattice_step.h: a -inf there must stay -inf,
+        // not turn into NaN): a lane's first live diagonal takes `emit`, sweep column 0 takes `skip`
+        if constexpr (MASKED) val = (d0 + k == ucol_first) ? emit : val;
+        val = col0 ? skip : val;
         RNNT_PIN();
         float Yn, Xn;
         if constexpr (BETA) { Yn = val; Xn = val; }
@@ -493,6 +500,7 @@ int logdomain_kernel_from_env() {
     const char* v = getenv("RNNT_LOGDOMAIN_KERNEL");
     if (v && v[0] == 'w' && v[1] == 's') return 1;
     if (v && v[0] == 'w' && v[1] == 'd') return 2;
+    if (v && v[0] == 'w' && v[1] == 'l') return 3;
     return 0;
 }
 std::atomic<int>& logdomain_kernel_setting() {
@@ -525,7 +533,7 @@ int last_lattice_kernel() { return g_last_kernel; }
 int logdomain_kernel() { return logdomain_kernel_setting().load(std::memory_order_relaxed); }
 
 int set_logdomain_kernel(int k) {
-    if (k < 0 || k > 2) return -1;
+    if (k < 0 || k > 3) return -1;
     return logdomain_kernel_setting().exchange(k, std::memory_order_relaxed);
 }
 
@@ -587,16 +595,25 @@ hipError_t launch_lattice(hipStream_t stream, const LatticeArgs& a, int N, int l
         // N=32, U=50: T=250 22.5 / 21.0, T=500 36.8 / 33.6, T=1000 64.8 / 58.6; N=256, T=500 42.7 / 34.5; T=1500, U=64
         // 93 / 84; profiles/r04_lattice_routes_single_block.txt).  RNNT_WD_LONE_FROM_T=<T>: only from that T on (A/B).
         static const int wd_lone_t = getenv("RNNT_WD_LONE_FROM_T") ? atoi(getenv("RNNT_WD_LONE_FROM_T")) : 0;
-        if (nA == 1 && !a.offs32 && kern != 1 && (kern == 2 || a.T >= wd_lone_t)) {
+        if (nA == 1 && kern != 1 && (kern == 2 || a.T >= wd_lone_t)) {
             const hipError_t e = launch_lattice_wd(stream, plain, N);
             g_last_kernel = 2;
             if (e != hipErrorNotSupported) return e;
         }
-        if (use_wd) {
+        if (use_wd && kern != 3) {
             const hipError_t e = launch_lattice_wd(stream, a, N);
             g_last_kernel = 2;
             if (e == hipSuccess) return redo_behind();
             if (e != hipErrorNotSupported) return e;
+        }
+        // Everything else that fits: the single-workgroup form of the same kernel (k_lattice_wl, round 5: three waves per
+        // column block, LDS-DMA loader, hand-written compute blocks, boundary columns through LDS), up to
+        // wl_max_blocks() column blocks.  us per alpha+beta launch, lattice_ws.hip / this (tools/lattice_routes.py,
+        // profiles/r05_lattice_routes.txt).  Needs nothing but the planes, so it also serves the callers without flags
+        // and rings (the reference-named C entry points, 32-bit compact offsets).
+        if (kern != 1 && nA >= 2) {
+            const hipError_t e = launch_lattice_wl(stream, plain, N, kern == 3 ? 5 : wl_max_blocks());
+            if (e != hipErrorNotSupported) { g_last_kernel = 5; return e; }
         }
         const hipError_t e = launch_lattice_ws(stream, plain, N);
         g_last_kernel = 1;

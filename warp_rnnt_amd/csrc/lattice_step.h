@@ -1,8 +1,8 @@
-// The log-domain lattice step shared by the two wave-specialised sweep kernels (lattice_ws.hip: all column blocks of
-// a sweep in one workgroup; lattice_wd.hip: one workgroup per column block).  One definition, so that both kernels
-// produce the same bits: K diagonals of lse(skip, emit) per call, lanes = lattice columns, the left neighbour's value
-// through one DPP wave_shr:1.  Reference counterpart: core_gather.cu:22-35 (log_sum_exp), :106-126 / :207-227 (the
-// per-cell recurrences).
+// The log-domain lattice step shared by the wave-specialised sweep kernels (lattice_ws.hip: all column blocks of a sweep
+// in one workgroup; lattice_wd.hip: one workgroup per column block, and its single-workgroup form k_lattice_wl).  One
+// definition, so that all of them produce the same bits: K diagonals of lse(skip, emit) per call, lanes = lattice columns,
+// the left neighbour's value through one DPP wave_shr:1.  Reference counterpart: core_gather.cu:22-35 (log_sum_exp),
+// :106-126 / :207-227 (the per-cell recurrences), :76-104 / :177-205 (the boundary row and column: plain sums).
 #pragma once
 #include "common.h"
 
@@ -37,22 +37,45 @@ __device__ __forceinline__ void block_barrier() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The cells on the rim of the lattice.  The reference does not run them through log_sum_exp: alpha[0,u] and beta[T-1,u]
+// are plain sums along the row (core_gather.cu:76-84, 177-185), alpha[t,0] and beta[t,U-1] plain sums along the column
+// (:86-104, 187-205).  A sweep that feeds them to lse(x, -inf) gets the same bits for every finite x -- max(x,-inf) +
+// log1p(exp(-inf)) = x + 0 -- which is what these kernels did until round 5; it gets NaN where x itself is -inf
+// (a masked label or blank on the rim: -inf - -inf), where the reference's sum stays -inf and the lattice behind the
+// cell stays finite.  So:
+//   * a lane's FIRST live diagonal (row 0 of alpha, row T-1 of beta in sweep coordinates; sweep column 0 excepted) takes
+//     `emit`.  Such diagonals only exist in the predicated blocks (MASKED): one compare + one select per step there;
+//   * sweep column 0 (lane 0 of the column block without a left neighbour: COL0) takes `skip` on every diagonal: one
+//     select per step, paid for by the v_mov that used to seed the DPP shift's lane 0 with -inf (wave_shr1_z needs none).
+// The interior keeps the reference's NaN: lse(-inf, -inf) = NaN there as in core_gather.cu:22-35.
+// ucol_chk: the lane's sweep column (0x40000000 for lanes without one).
+__device__ __forceinline__ int first_diag_of(const int ucol_chk) { return ucol_chk == 0 ? 0x40000001 : ucol_chk; }
+
 // K diagonals of the compute wave.  cur = this block's pairs (registers).  Values go to LDS.
-template <bool BETA, bool MASKED, bool MAIL>
+// COL0: this wave's lane 0 is sweep column 0 (no left neighbour; mvec is not read).
+template <bool BETA, bool MASKED, bool MAIL, bool COL0>
 __device__ __forceinline__ void compute_block(const f32x2 (&cur)[K], const float mvec, float& Y, float& X,
                                               const int d0, const int ucol_chk, const int Tn,
                                               float* vslot /* [K][WAVE] + lane */, float* mail_slot) {
     float first[K];
+    if constexpr (!COL0) {
 #pragma unroll
-    for (int k = 0; k < K; ++k) first[k] = readlane(mvec, k);
+        for (int k = 0; k < K; ++k) first[k] = readlane(mvec, k);
+    }
+    const int ucol_first = first_diag_of(ucol_chk);
+    const bool col0 = ucol_chk == 0;
 #define RNNT_PIN() __builtin_amdgcn_sched_barrier(0)
     // A lone wave issues one instruction per ~5.8 cycles whatever it is (tools/ubench/step_order.hip),
     // so the step is ordered to need NO hazard nops: the LDS write and the next skip/Y add sit between
     // the value and the DPP that reads it (2 wait states), v_max sits behind v_exp_f32 (1 wait state),
     // and the v_mov that seeds the next DPP's lane 0 is issued well before it.
-    float fk = first[0];
-    asm volatile("" : "+v"(fk));   // materialise the DPP's lane-0 seed in a VGPR here, not next to the DPP
-    RNNT_PIN();
+    float fk = 0.0f;
+    if constexpr (!COL0) {
+        fk = first[0];
+        asm volatile("" : "+v"(fk));   // materialise the DPP's lane-0 seed in a VGPR here, not next to the DPP
+        RNNT_PIN();
+    }
     float pval = 0.0f;
 #pragma unroll
     for (int k = 0; k < K; ++k) {
@@ -71,7 +94,8 @@ __device__ __forceinline__ void compute_block(const f32x2 (&cur)[K], const float
         } else {
             skip = Y;
         }
-        const float left = wave_shr1(fk, X);                                           // chain
+        float left;
+        if constexpr (COL0) left = wave_shr1_z(X); else left = wave_shr1(fk, X);      // chain
         RNNT_PIN();
         if constexpr (BETA) {
             emit = left + cur[k].y;                                                    // chain (scalar add: the
@@ -83,6 +107,8 @@ __device__ __forceinline__ void compute_block(const f32x2 (&cur)[K], const float
         // lse(skip, emit) = max + log1p(exp(-|skip-emit|)), see lattice.hip
         const float t = skip - emit;                                                   // chain
         RNNT_PIN();
+        bool rim = false;                                                              // (compared here, two wait states
+        if constexpr (MASKED) { rim = d0 + k == ucol_first; RNNT_PIN(); }              //  ahead of the select that reads it)
         const float m = -__builtin_fabsf(t) * 1.44269504088896340736f;                 // chain
         RNNT_PIN();
         const float e = __builtin_amdgcn_exp2f(m);                                     // chain
@@ -93,15 +119,19 @@ __device__ __forceinline__ void compute_block(const f32x2 (&cur)[K], const float
         RNNT_PIN();
         const float l2 = __builtin_amdgcn_logf(u);                                     // chain
         RNNT_PIN();
-        if (k + 1 < K) { fk = first[k + 1]; asm volatile("" : "+v"(fk)); RNNT_PIN(); }
+        if constexpr (!COL0) {
+            if (k + 1 < K) { fk = first[k + 1]; asm volatile("" : "+v"(fk)); RNNT_PIN(); }
+        }
         const float um1 = u - 1.0f;
         RNNT_PIN();
         const float c = e - um1;
         RNNT_PIN();
         const float l = __builtin_fmaf(l2, 0.693147180559945309417f, c);               // chain
         RNNT_PIN();
-        const float val = mx + l;                                                      // chain
+        float val = mx + l;                                                            // chain
         RNNT_PIN();
+        if constexpr (MASKED) { val = rim ? emit : val; RNNT_PIN(); }                    // rim: first live diagonal
+        if constexpr (COL0) { val = col0 ? skip : val; RNNT_PIN(); }                       // rim: sweep column 0
         float Yn, Xn;
         if constexpr (BETA) {
             Yn = val; Xn = val;
@@ -134,90 +164,203 @@ __device__ __forceinline__ void compute_block(const f32x2 (&cur)[K], const float
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// The same K diagonals -- same instructions on the dependent chain, same bits -- for lattice_wd.hip, with everything a
-// block needs from LDS fetched IN PLACE one block ahead:
-//   * the pair of diagonal k is dead once step k has used it: step k reloads cur[k] with the next block's pair k;
+// The same diagonals -- same operations in the same order, same bits -- for lattice_wd.hip, KK of them per call, with
+// everything a block needs from LDS fetched IN PLACE one block ahead:
+//   * the pairs of two consecutive diagonals share a register quad (cur2[j] = {pair 2j, pair 2j+1}); once step 2j+1 has
+//     used it, ONE ds_read2st64_b64 refills it with the next block's two pairs (the rows of a block are 512 bytes apart:
+//     the instruction's stride);
 //   * SEEDED (the column block has a left neighbour): seed[k] holds the neighbour's boundary value for step k in
 //     every lane (a broadcast LDS read; only lane 0's copy matters: it is the `old` operand of the DPP shift, which
-//     lane 0 keeps).  The DPP consumes it, step k reloads it with the next block's value.  No v_readlane / v_mov pair
-//     per step, no exposed LDS round trip at the head of the block.
-// One buffer each = one copy of the block per variant in the instruction stream (a register ping-pong needs the loop
-// unrolled twice), which matters for instruction fetch at the head of a column block.
-// The reloads are inline assembly (as C++ the compiler loads into fresh registers and copies them over at the head of the
-// loop: sixteen v_mov and eight waits per block on the wave whose instruction count IS the sweep's critical path), so
-// they are not counted by the compiler: the caller must not let a block start before an `s_waitcnt lgkmcnt(0)` it can
-// rely on -- the block barrier's (this wave has LDS writes of its own pending in front of every barrier, so the release
-// fence always carries one).
-template <int OFF>
-__device__ __forceinline__ void lds_reload_b64(f32x2& dst, const unsigned lds_byte_addr) {
-    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(dst) : "v"(lds_byte_addr), "n"(OFF));
+//     lane 0 keeps).  The DPP consumes it, step k reloads it with the next block's value.  Not SEEDED = sweep column 0
+//     is this wave's lane 0 (COL0 above).
+// One buffer each = one copy of the block per variant in the instruction stream.
+// The reloads are inline assembly, so they are not counted by the compiler: the caller must not let a block start before
+// an `s_waitcnt lgkmcnt(0)` of its own (lattice_wd.hip: in front of every barrier of the compute wave).
+//
+// Two bodies.  The predicated block (MASKED: lanes start or finish inside it -- a few blocks at either end of a column
+// block's life) is C++.  The block every lane is live in -- nine tenths of a long sweep, and the sweep runs at the pace of
+// its slowest wave -- is written instruction by instruction (round 5), because a lone wave issues one instruction every
+// ~5.8 cycles whatever it is, so the sweep's time IS that wave's instruction count, and the compiler's version carried
+// three to four instructions per diagonal that do nothing for the result:
+//   * fmaxf(a, b) is up to three v_max_f32: the compiler quiets signalling NaNs first (v_max x, x, x) on every operand it
+//     cannot prove to be the result of an arithmetic instruction -- the DPP shift's output always -- which made the
+//     alpha sweep two instructions per diagonal longer than the beta sweep.  Nothing on the chain produces a signalling
+//     NaN, and a quiet one ends in val = NaN whatever the max returns (l is NaN then): one v_max_f32;
+//   * a v_mov per diagonal that copied the (wave-uniform) address of the seeds from an SGPR into a VGPR for the reload;
+//   * the column block without a left neighbour seeded lane 0 of the shift with -inf through a v_mov per diagonal: here
+//     the shift is folded into the instructions that consume it (v_sub_f32_dpp / v_max_f32_dpp / v_add_f32_dpp with
+//     bound_ctrl: lane 0 reads 0.0), and lane 0 -- sweep column 0, whose value is `skip` by the rim rule -- is put right
+//     by one v_cndmask;
+//   * (an asm statement in the middle of compiler code costs an s_nop at its end -- the compiler pads one wait state
+//     before the first use of anything an asm statement wrote -- hence whole steps, seed reload included.
+//     The one thing left to the compiler between two steps is the store of the value: an instruction it can see, which
+//     therefore counts as that wait state.)
+// Per diagonal: 14 VALU/LDS instructions + half a reload of pairs, against 17-18.
+// Hazards kept by construction (the compiler does not look inside): >= 2 instructions between the VALU write of the
+// value handed right and the DPP read of it (the store + one add), one instruction between v_exp_f32 / v_log_f32 and the
+// first ordinary VALU read of their result (v_max; v_add + v_sub).
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <int OFF0>
+__device__ __forceinline__ void lds_reload_2rows(f32x4& dst, const unsigned lds_byte_addr) {
+    // rows OFF0 and OFF0 + 1 of a [KK][WAVE] block of pairs, this lane's column: two 8-byte reads 64 x 8 bytes apart
+    asm volatile("ds_read2st64_b64 %0, %1 offset0:%2 offset1:%3" : "=v"(dst) : "v"(lds_byte_addr), "n"(OFF0), "n"(OFF0 + 1));
 }
 template <int OFF>
 __device__ __forceinline__ void lds_reload_b32(float& dst, const unsigned lds_byte_addr) {
     asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(dst) : "v"(lds_byte_addr), "n"(OFF));
 }
-// (k is a constant once the caller's loop is unrolled; the offset has to be one for the assembler)
-__device__ __forceinline__ void reload_pair(f32x2& dst, const unsigned nsrc, const int k) {
-    constexpr int ROW = WAVE * 8;
-    switch (k) {
-        case 0: lds_reload_b64<0 * ROW>(dst, nsrc); break;
-        case 1: lds_reload_b64<1 * ROW>(dst, nsrc); break;
-        case 2: lds_reload_b64<2 * ROW>(dst, nsrc); break;
-        case 3: lds_reload_b64<3 * ROW>(dst, nsrc); break;
-        case 4: lds_reload_b64<4 * ROW>(dst, nsrc); break;
-        case 5: lds_reload_b64<5 * ROW>(dst, nsrc); break;
-        case 6: lds_reload_b64<6 * ROW>(dst, nsrc); break;
-        default: lds_reload_b64<7 * ROW>(dst, nsrc); break;
+__device__ __forceinline__ void wait_lds() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
+#define RNNT_LSE_TAIL(T, E, MX, U)                                                                                      \
+    "v_add_f32 " U ", 1.0, " E "\n\t"                                                                                    \
+    "v_log_f32 " T ", " U "\n\t"                                                                                         \
+    "v_add_f32 " U ", -1.0, " U "\n\t"                                                                                   \
+    "v_sub_f32 " E ", " E ", " U "\n\t"                                                                                  \
+    "v_fmac_f32 " E ", 0x3f317218, " T "\n\t"
+#define RNNT_DPP " wave_shr:1 row_mask:0xf bank_mask:0xf"
+
+// One diagonal of a block every lane is live in; returns the cell's value (the caller stores it: a store the compiler can
+// see, between two statements -- see above).  K_ = the diagonal's index in the block (the seed's LDS offset).
+// alpha: Y = alpha + blank log-prob of the own previous cell, X = alpha + label log-prob (handed right).
+template <int K_, bool SEEDED>
+__device__ __forceinline__ float alpha_step(float& Y, float& X, float& sd, const float cx, const float cy,
+                                            const unsigned nseed_v, const float log2e, const unsigned long long col0_mask) {
+    float t, e, val, u;
+    if constexpr (SEEDED) {
+        asm volatile("v_mov_b32_dpp %2, %1" RNNT_DPP "\n\t"          // emit: lane i <- X of lane i-1, lane 0 keeps its seed
+                     "v_sub_f32 %3, %0, %2\n\t"                      // t = skip - emit
+                     "v_mul_f32_e64 %3, -|%3|, %9\n\t"
+                     "v_exp_f32 %4, %3\n\t"
+                     "v_max_f32 %5, %0, %2\n\t"
+                     "ds_read_b32 %2, %10 offset:%11\n\t"            // the seed is spent: the next block's, in place
+                     RNNT_LSE_TAIL("%3", "%4", "%5", "%6")
+                     "v_add_f32 %5, %5, %4\n\t"                      // val = max + l
+                     "v_add_f32 %1, %5, %8\n\t"                      // X = val + label log-prob
+                     "v_add_f32 %0, %5, %7"                           // Y = val + blank log-prob
+                     : "+v"(Y), "+v"(X), "+v"(sd), "=&v"(t), "=&v"(e), "=&v"(val), "=&v"(u)
+                     : "v"(cx), "v"(cy), "s"(log2e), "v"(nseed_v), "n"(K_ * 4));
+    } else {
+        asm volatile("v_sub_f32_dpp %2, %1, %0" RNNT_DPP " bound_ctrl:1\n\t"   // t = emit - skip (lane 0: 0 - skip, unused)
+                     "v_mul_f32_e64 %2, -|%2|, %8\n\t"
+                     "v_exp_f32 %3, %2\n\t"
+                     "v_max_f32_dpp %4, %1, %0" RNNT_DPP " bound_ctrl:1\n\t"
+                     RNNT_LSE_TAIL("%2", "%3", "%4", "%5")
+                     "v_add_f32 %4, %4, %3\n\t"
+                     "v_cndmask_b32_e64 %4, %4, %0, %9\n\t"         // sweep column 0 (lane 0): the rim takes skip
+                     "v_add_f32 %1, %4, %7\n\t"
+                     "v_add_f32 %0, %4, %6"
+                     : "+v"(Y), "+v"(X), "=&v"(t), "=&v"(e), "=&v"(val), "=&v"(u)
+                     : "v"(cx), "v"(cy), "s"(log2e), "s"(col0_mask));
+        (void)sd; (void)nseed_v;
     }
-    static_assert(K == 8, "one case per diagonal of a block");
+    return val;
 }
-__device__ __forceinline__ void reload_seed(float& dst, const unsigned nseed, const int k) {
-    switch (k) {
-        case 0: lds_reload_b32<0>(dst, nseed); break;
-        case 1: lds_reload_b32<4>(dst, nseed); break;
-        case 2: lds_reload_b32<8>(dst, nseed); break;
-        case 3: lds_reload_b32<12>(dst, nseed); break;
-        case 4: lds_reload_b32<16>(dst, nseed); break;
-        case 5: lds_reload_b32<20>(dst, nseed); break;
-        case 6: lds_reload_b32<24>(dst, nseed); break;
-        default: lds_reload_b32<28>(dst, nseed); break;
+// beta: V = beta of the own previous cell = what is handed right = the value.
+template <int K_, bool SEEDED>
+__device__ __forceinline__ void beta_step(float& V, float& sd, const float cx, const float cy, const unsigned nseed_v,
+                                          const float log2e, const unsigned long long col0_mask) {
+    float sk, t, e, u;
+    if constexpr (SEEDED) {
+        asm volatile("v_add_f32 %2, %0, %6\n\t"                      // skip = beta[t+1,u] + blank log-prob
+                     "v_mov_b32_dpp %1, %0" RNNT_DPP "\n\t"          // left
+                     "v_add_f32 %1, %1, %7\n\t"                      // emit = beta[t,u+1] + label log-prob
+                     "v_sub_f32 %3, %2, %1\n\t"
+                     "v_mul_f32_e64 %3, -|%3|, %8\n\t"
+                     "v_exp_f32 %4, %3\n\t"
+                     "v_max_f32 %2, %2, %1\n\t"
+                     "ds_read_b32 %1, %9 offset:%10\n\t"             // the seed is spent: the next block's, in place
+                     RNNT_LSE_TAIL("%3", "%4", "%2", "%5")
+                     "v_add_f32 %0, %2, %4"
+                     : "+v"(V), "+v"(sd), "=&v"(sk), "=&v"(t), "=&v"(e), "=&v"(u)
+                     : "v"(cx), "v"(cy), "s"(log2e), "v"(nseed_v), "n"(K_ * 4));
+    } else {
+        float em;
+        asm volatile("v_add_f32 %1, %0, %6\n\t"                      // skip
+                     "v_add_f32_dpp %2, %0, %7" RNNT_DPP " bound_ctrl:1\n\t"   // emit (lane 0: 0 + label log-prob, unused)
+                     "v_sub_f32 %3, %1, %2\n\t"
+                     "v_mul_f32_e64 %3, -|%3|, %8\n\t"
+                     "v_exp_f32 %4, %3\n\t"
+                     "v_max_f32 %2, %1, %2\n\t"
+                     RNNT_LSE_TAIL("%3", "%4", "%2", "%5")
+                     "v_add_f32 %0, %2, %4\n\t"
+                     "v_cndmask_b32_e64 %0, %0, %1, %9"              // sweep column 0 (lane 0): the rim takes skip
+                     : "+v"(V), "=&v"(sk), "=&v"(em), "=&v"(t), "=&v"(e), "=&v"(u)
+                     : "v"(cx), "v"(cy), "s"(log2e), "s"(col0_mask));
+        (void)sd; (void)nseed_v;
+    }
+}
+#undef RNNT_LSE_TAIL
+#undef RNNT_DPP
+
+// steps [K_, KK) of a block, recursively (every LDS offset has to be an immediate)
+template <int KK, int K_, bool BETA, bool SEEDED>
+__device__ __forceinline__ void fast_steps(f32x4 (&cur2)[KK / 2], float (&seed)[KK], const unsigned nsrc, const unsigned nseed_v,
+                                           float& Y, float& X, float* vslot, const float log2e,
+                                           const unsigned long long col0_mask) {
+    if constexpr (K_ < KK) {
+        const float cx = (K_ & 1) ? cur2[K_ / 2].z : cur2[K_ / 2].x;
+        const float cy = (K_ & 1) ? cur2[K_ / 2].w : cur2[K_ / 2].y;
+        if constexpr (BETA) {
+            beta_step<K_, SEEDED>(X, seed[K_], cx, cy, nseed_v, log2e, col0_mask);
+            vslot[K_ * WAVE] = X;       // (this store and the next step's first add sit between the value and its DPP read)
+        } else {
+            vslot[K_ * WAVE] = alpha_step<K_, SEEDED>(Y, X, seed[K_], cx, cy, nseed_v, log2e, col0_mask);
+        }                               // (alpha: the add of Y and this store sit between X and its DPP read)
+        if constexpr ((K_ & 1) != 0) lds_reload_2rows<K_ - 1>(cur2[K_ / 2], nsrc);       // next block's pairs K_ - 1, K_
+        fast_steps<KK, K_ + 1, BETA, SEEDED>(cur2, seed, nsrc, nseed_v, Y, X, vslot, log2e, col0_mask);
     }
 }
 
-template <bool BETA, bool MASKED, bool MAIL, bool SEEDED>
-__device__ __forceinline__ void compute_block_ip(f32x2 (&cur)[K], float (&seed)[K], const unsigned nsrc, const unsigned nseed,
+// nsrc / nseed: LDS byte addresses of the next block's pairs (this lane's column) and seeds; vslot: this block's slot of
+// the value ring, [KK][WAVE] + lane.  BETA keeps one state (X; Y is not used).
+template <int KK, bool BETA, bool MASKED, bool SEEDED>
+__device__ __forceinline__ void compute_block_ip(f32x4 (&cur2)[KK / 2], float (&seed)[KK], const unsigned nsrc, const unsigned nseed,
                                                  float& Y, float& X, const int d0, const int ucol_chk, const int Tn,
-                                                 float* vslot /* [K][WAVE] + lane */, float* mail_slot) {
+                                                 float* vslot) {
+    static_assert(KK == 8 || KK == 16, "blocks of 8 or 16 diagonals");
+    // the seeds' LDS address in a VGPR the compiler cannot see through: it is wave-uniform, and left to itself the
+    // compiler keeps it in an SGPR and copies it into a VGPR in front of EVERY reload (one v_mov per diagonal)
+    unsigned nseed_v = nseed;
+    if constexpr (SEEDED) asm volatile("" : "+v"(nseed_v));
+    if constexpr (!MASKED) {
+        fast_steps<KK, 0, BETA, SEEDED>(cur2, seed, nsrc, nseed_v, Y, X, vslot, 1.44269504088896340736f, 1ull);
+        if constexpr (BETA) Y = X;
+        return;
+    }
 #define RNNT_PIN() __builtin_amdgcn_sched_barrier(0)
     // (the order of the step is compute_block's: no hazard nops, see there)
-    float fk = -__builtin_inff();
-    if constexpr (!SEEDED) { asm volatile("" : "+v"(fk)); RNNT_PIN(); }   // the DPP's lane-0 seed, in a VGPR ahead of the DPP
+    const int ucol_first = first_diag_of(ucol_chk);
+    const bool col0 = ucol_chk == 0;
     float pval = 0.0f;
 #pragma unroll
-    for (int k = 0; k < K; ++k) {
+    for (int k = 0; k < KK; ++k) {
+        const float cx = (k & 1) ? cur2[k / 2].z : cur2[k / 2].x;
+        const float cy = (k & 1) ? cur2[k / 2].w : cur2[k / 2].y;
         float skip, emit;
         if constexpr (BETA) {
             if (k > 0) {
                 vslot[(k - 1) * WAVE] = pval;
                 RNNT_PIN();
             }
-            skip = Y + cur[k].x;
+            skip = Y + cx;
             RNNT_PIN();
         } else {
             skip = Y;
         }
-        const float left = wave_shr1(SEEDED ? seed[k] : fk, X);                        // chain
+        float left;
+        if constexpr (SEEDED) left = wave_shr1(seed[k], X); else left = wave_shr1_z(X);   // chain
         RNNT_PIN();
         if constexpr (BETA) {
-            emit = left + cur[k].y;                                                    // chain
-            RNNT_PIN();
-            reload_pair(cur[k], nsrc, k);                                              // next block's pair k
+            emit = left + cy;                                                          // chain
         } else {
             emit = left;
         }
         RNNT_PIN();
         const float t = skip - emit;                                                   // chain
         RNNT_PIN();
+        const bool rim = d0 + k == ucol_first;                                         // (compared here, two wait states
+        RNNT_PIN();                                                                    //  ahead of the select that reads it)
         const float m = -__builtin_fabsf(t) * 1.44269504088896340736f;                 // chain
         RNNT_PIN();
         const float e = __builtin_amdgcn_exp2f(m);                                     // chain
@@ -228,44 +371,56 @@ __device__ __forceinline__ void compute_block_ip(f32x2 (&cur)[K], float (&seed)[
         RNNT_PIN();
         const float l2 = __builtin_amdgcn_logf(u);                                     // chain
         RNNT_PIN();
-        if constexpr (SEEDED) {
-            reload_seed(seed[k], nseed, k);                                            // next block's boundary value k
-            RNNT_PIN();
-        } else if (k + 1 < K) {
-            fk = -__builtin_inff(); asm volatile("" : "+v"(fk)); RNNT_PIN();
-        }
         const float um1 = u - 1.0f;
         RNNT_PIN();
         const float c = e - um1;
         RNNT_PIN();
         const float l = __builtin_fmaf(l2, 0.693147180559945309417f, c);               // chain
         RNNT_PIN();
-        const float val = mx + l;                                                      // chain
+        float val = mx + l;                                                            // chain
         RNNT_PIN();
+        val = rim ? emit : val;                                                        // rim: first live diagonal
+        RNNT_PIN();
+        if constexpr (SEEDED) {
+            switch (k) {   // next block's boundary value k (the seed's register is `emit` up to here)
+                case 0: lds_reload_b32<0>(seed[k], nseed_v); break;   case 1: lds_reload_b32<4>(seed[k], nseed_v); break;
+                case 2: lds_reload_b32<8>(seed[k], nseed_v); break;   case 3: lds_reload_b32<12>(seed[k], nseed_v); break;
+                case 4: lds_reload_b32<16>(seed[k], nseed_v); break;  case 5: lds_reload_b32<20>(seed[k], nseed_v); break;
+                case 6: lds_reload_b32<24>(seed[k], nseed_v); break;  case 7: lds_reload_b32<28>(seed[k], nseed_v); break;
+                case 8: lds_reload_b32<32>(seed[k], nseed_v); break;  case 9: lds_reload_b32<36>(seed[k], nseed_v); break;
+                case 10: lds_reload_b32<40>(seed[k], nseed_v); break; case 11: lds_reload_b32<44>(seed[k], nseed_v); break;
+                case 12: lds_reload_b32<48>(seed[k], nseed_v); break; case 13: lds_reload_b32<52>(seed[k], nseed_v); break;
+                case 14: lds_reload_b32<56>(seed[k], nseed_v); break; default: lds_reload_b32<60>(seed[k], nseed_v); break;
+            }
+            RNNT_PIN();
+        }
+        if constexpr (!SEEDED) { val = col0 ? skip : val; RNNT_PIN(); }                // rim: sweep column 0
         float Yn, Xn;
         if constexpr (BETA) {
             Yn = val; Xn = val;
         } else {
-            Xn = val + cur[k].y;                                                       // chain (feeds the DPP)
+            Xn = val + cy;                                                             // chain (feeds the DPP)
             RNNT_PIN();
             vslot[k * WAVE] = val;
             RNNT_PIN();
-            Yn = val + cur[k].x;
-            RNNT_PIN();
-            reload_pair(cur[k], nsrc, k);                                              // next block's pair k
+            Yn = val + cx;
             RNNT_PIN();
         }
-        if constexpr (MASKED) {
-            const bool live = (unsigned)(d0 + k - ucol_chk) < (unsigned)Tn;
-            Y = live ? Yn : Y;
-            X = live ? Xn : X;
-        } else {
-            Y = Yn; X = Xn;
+        if (k & 1) {                                                                   // next block's pairs k - 1, k
+            switch (k) {
+                case 1: lds_reload_2rows<0>(cur2[k / 2], nsrc); break;   case 3: lds_reload_2rows<2>(cur2[k / 2], nsrc); break;
+                case 5: lds_reload_2rows<4>(cur2[k / 2], nsrc); break;   case 7: lds_reload_2rows<6>(cur2[k / 2], nsrc); break;
+                case 9: lds_reload_2rows<8>(cur2[k / 2], nsrc); break;   case 11: lds_reload_2rows<10>(cur2[k / 2], nsrc); break;
+                case 13: lds_reload_2rows<12>(cur2[k / 2], nsrc); break; default: lds_reload_2rows<14>(cur2[k / 2], nsrc); break;
+            }
+            RNNT_PIN();
         }
+        const bool live = (unsigned)(d0 + k - ucol_chk) < (unsigned)Tn;
+        Y = live ? Yn : Y;
+        X = live ? Xn : X;
         pval = val;
-        if constexpr (MAIL) { mail_slot[k] = X; RNNT_PIN(); }
     }
-    if constexpr (BETA) vslot[(K - 1) * WAVE] = pval;
+    if constexpr (BETA) vslot[(KK - 1) * WAVE] = pval;
 #undef RNNT_PIN
 }
 

@@ -43,6 +43,8 @@
 // Values handed over are the compute wave's own fp32 X registers, so the results are bit-identical to
 // lattice_ws.hip's whatever the placement and timing (tests/test_gpu_wd.py).
 #include <algorithm>
+#include <atomic>
+#include <cstdlib>
 #include <type_traits>
 
 #include "common.h"
@@ -53,13 +55,16 @@ namespace rnnt {
 
 namespace wd {
 
-using ws::K;
+#ifndef RNNT_WD_K
+#define RNNT_WD_K 8
+#endif
+constexpr int K = RNNT_WD_K;           // diagonals per block = per interval = per s_barrier (8 or 16; lattice_ws.hip: 8)
 using ws::f32x2;
 using ws::block_barrier;
 using ws::compute_block_ip;
 using ws::RSRC_WORD3;
 using ws::OOB;
-using ws::TRASH;
+constexpr int TRASH = WAVE + K;
 
 #ifndef RNNT_WD_DLOAD
 #define RNNT_WD_DLOAD 2
@@ -77,6 +82,9 @@ static_assert(DLOAD >= 2 && DLOAD + 2 <= MIN_SLOTS, "ring depths");
 constexpr int SPIN_LIMIT = RNNT_WD_SPIN_LIMIT;   // polls before a hand-over is declared lost (seconds)
 #ifndef RNNT_WD_LAG
 #define RNNT_WD_LAG 1
+#endif
+#ifndef RNNT_WL_DEFAULT_MAX_BLOCKS
+#define RNNT_WL_DEFAULT_MAX_BLOCKS 2
 #endif
 constexpr int LAG = RNNT_WD_LAG; // blocks a column block lets its left neighbour get ahead once it has caught up with it
 
@@ -132,15 +140,21 @@ __device__ __forceinline__ unsigned lds_addr(const void* p) {
     return __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) const char*)p);
 }
 
-template <bool BETA, bool COMPACT, bool HAS_LEFT, bool HAS_RIGHT>
+// LOCAL: the single-workgroup form (k_lattice_wl below).  All column blocks of the sweep are waves of THIS workgroup and
+// meet at every barrier, column block idx running L_LOCAL intervals behind its left neighbour; the boundary column
+// goes from the left block's storer straight into the right block's `mail_vals` (sm_right) -- no ring, no tag, no poll,
+// nothing in global memory, no preparation launch in front and no redo launch behind.  Everything else (the loader's
+// LDS-DMA, the in-place compute blocks, the store-only storer, the dry run) is the code of the distributed form.
+constexpr int L_LOCAL = 3;   // a boundary value computed in interval g is stored to the neighbour's LDS by the storer in
+                             // g + 1 and read (in place, one block ahead) by the neighbour's compute wave in g + 2
+template <bool BETA, bool COMPACT, bool HAS_LEFT, bool HAS_RIGHT, bool LOCAL>
 __device__ __forceinline__ void sweep(const LatticeArgs& a, const Item it, const UttLens len, const int nA, Smem& sm,
-                                      int* wg_bad) {
+                                      Smem* sm_right, int* wg_bad, const int role /* 0 compute, 1 loader, 2 storer */) {
     const int n = it.n, idx = it.cb;
     const int Tn = len.Tn, Un = len.Un;
     const int T = COMPACT ? Tn : a.T, U = COMPACT ? Un : a.U;
     const int lane = threadIdx.x & (WAVE - 1);
-    const int role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // 0 compute, 1 loader, 2 storer
-    const size_t nbase = COMPACT ? (size_t)a.offs[n] : (size_t)n * T * U;
+    const size_t nbase = COMPACT ? compact_base(a, n) : (size_t)n * T * U;
     float* out = (BETA ? a.betas : a.alphas) + nbase;
     if (Un == 1) {   // no labels: prefix / suffix sums by one wave of the first column block's workgroup
         if (idx == 0 && role == 0) {
@@ -176,8 +190,8 @@ __device__ __forceinline__ void sweep(const LatticeArgs& a, const Item it, const
     // hand-over rings in global memory: one per (sweep, column-block boundary)
     const size_t sweep_id = (size_t)2 * n + (BETA ? 1 : 0);
     const size_t pitch = ring_pitch(a.T, a.U);
-    u64* ring_in = HAS_LEFT ? a.mail + (sweep_id * (nA - 1) + (idx - 1)) * pitch : nullptr;
-    u64* ring_out = HAS_RIGHT ? a.mail + (sweep_id * (nA - 1) + idx) * pitch : nullptr;
+    u64* ring_in = HAS_LEFT && !LOCAL ? a.mail + (sweep_id * (nA - 1) + (idx - 1)) * pitch : nullptr;
+    u64* ring_out = HAS_RIGHT && !LOCAL ? a.mail + (sweep_id * (nA - 1) + idx) * pitch : nullptr;
     const unsigned tag_in = ring_tag(a.epoch, (unsigned)(sweep_id * (nA - 1) + (idx - 1)));
     const unsigned tag_out = ring_tag(a.epoch, (unsigned)(sweep_id * (nA - 1) + idx));
     (void)ring_in; (void)ring_out; (void)tag_in; (void)tag_out;
@@ -198,7 +212,8 @@ __device__ __forceinline__ void sweep(const LatticeArgs& a, const Item it, const
     if (role == 1) {
         // ------------------------------ loader wave ------------------------------
         const i32x4 rs_lp = make_rsrc(reinterpret_cast<const float2*>(a.lp) + nbase, (unsigned)((size_t)T * U * 8));
-        const i32x4 rs_ring = make_rsrc(ring_in, HAS_LEFT ? (unsigned)(pitch * 8) : 0u);
+        constexpr bool RING_IN = HAS_LEFT && !LOCAL;           // the neighbour's column arrives through an L2 ring
+        const i32x4 rs_ring = make_rsrc(ring_in, RING_IN ? (unsigned)(pitch * 8) : 0u);
         const unsigned lds_pairs = lds_addr(&sm.pairs[0][0][0]);
         const unsigned lds_raw = lds_addr(&sm.mail_raw[0][0]);
         const int rowb = U * 8;
@@ -206,7 +221,7 @@ __device__ __forceinline__ void sweep(const LatticeArgs& a, const Item it, const
         const int colb = (cwin + 2 * (lane & 31)) * 8;         // 16 bytes = two columns
         int row_ld = row0;                                     // row of the first diagonal of the next block to fetch
         int slot_ld = 0;                                       // its slot in the LDS ring (block lo = slot 0)
-        constexpr int NDMA = 4 + (HAS_LEFT ? 1 : 0);           // pieces per interval, always all of them
+        constexpr int NDMA = K / 2 + (RING_IN ? 1 : 0);        // pieces per interval, always all of them
         // per-lane part of a piece's offset while the K rows of a block do not wrap around the plane (the rule): column
         // + this lane's diagonal relative to the block's lowest row, which goes into the scalar offset
         int voff_j[K / 2];
@@ -237,7 +252,7 @@ __device__ __forceinline__ void sweep(const LatticeArgs& a, const Item it, const
         for (int p = p0; p < p1; ++p) {
             RNNT_WD_STAMP(p, 2);
             wait_vmcnt<NDMA * (DLOAD - 1)>();                  // everything fetched DLOAD intervals ago has landed
-            if constexpr (HAS_LEFT) {
+            if constexpr (RING_IN) {
                 const int m = p;
                 if (m >= lo && m < hi_left) {
                     u64 g = sm.mail_raw[m & (MIN_SLOTS - 1)][mlane];
@@ -287,7 +302,7 @@ __device__ __forceinline__ void sweep(const LatticeArgs& a, const Item it, const
                     slot_ld = slot_ld + 1 == PSLOTS ? 0 : slot_ld + 1;
                 }
             }
-            if constexpr (HAS_LEFT) {
+            if constexpr (RING_IN) {
                 const int ml = p + DLOAD;
                 const int mm = (ml >= lo && ml < hi_left) ? ml : lo;   // (always a block of the ring: the piece is
                                                                         //  issued regardless, its bytes not looked at)
@@ -309,7 +324,7 @@ __device__ __forceinline__ void sweep(const LatticeArgs& a, const Item it, const
         const bool dry = role == 2;
         float Y = (ucol == 0) ? 0.0f : NEG_INF;
         float X = NEG_INF;
-        f32x2 cur[K];
+        ws::f32x4 cur2[K / 2];                                 // pairs of diagonals 2j, 2j+1: (x, y) and (z, w)
         float seed[K];
         // Blocks [lo, head_end) and [full_end, hi) have lanes that start or finish inside them (predicated variant),
         // [head_end, full_end) have every lane that owns a column live throughout (lanes beyond the last column run
@@ -323,14 +338,21 @@ __device__ __forceinline__ void sweep(const LatticeArgs& a, const Item it, const
             lb = idx > 0 ? -2 : -1;
             head_end = -1; full_end = 0; tail_end = 0;
 #pragma unroll
-            for (int k = 0; k < K; ++k) { cur[k] = f32x2{-1.0f, -2.0f}; seed[k] = -3.0f; }
+            for (int k = 0; k < K; ++k) seed[k] = -3.0f;
+#pragma unroll
+            for (int j = 0; j < K / 2; ++j) cur2[j] = ws::f32x4{-1.0f, -2.0f, -1.0f, -2.0f};
         } else {
             // block lb is computed during interval lb + 2: its pairs and the neighbour's block have landed and are
             // checked by the end of interval lb
             for (int t = p0; t < lo + 1; ++t) block_barrier();
             const f32x2* src = &sm.pairs[0][0][pos];
 #pragma unroll
-            for (int k = 0; k < K; ++k) { cur[k] = src[k * WAVE]; seed[k] = HAS_LEFT ? sm.mail_vals[lo & (MIN_SLOTS - 1)][k] : NEG_INF; }
+            for (int k = 0; k < K; ++k) seed[k] = HAS_LEFT ? sm.mail_vals[lo & (MIN_SLOTS - 1)][k] : NEG_INF;
+#pragma unroll
+            for (int j = 0; j < K / 2; ++j) {
+                const f32x2 a0 = src[(2 * j) * WAVE], a1 = src[(2 * j + 1) * WAVE];
+                cur2[j] = ws::f32x4{a0.x, a0.y, a1.x, a1.y};
+            }
             block_barrier();
             lb = lo;
             head_end = fb0 < fb1 ? fb0 : hi; full_end = fb0 < fb1 ? fb1 : head_end; tail_end = hi;
@@ -347,9 +369,16 @@ __device__ __forceinline__ void sweep(const LatticeArgs& a, const Item it, const
             const unsigned nseed = seeds0 + (unsigned)((lb + 1) & (MIN_SLOTS - 1)) * (K * 4);
             float* vslot = &sm.vals[lb & (VSLOTS - 1)][0][lane];
             // (no mailbox write on this wave: the storer rebuilds the boundary column from the values)
-            compute_block_ip<BETA, MASKED, false, HAS_LEFT>(cur, seed, nsrc, nseed, Y, X, d0, ucol_chk, Tn, vslot, nullptr);
+            compute_block_ip<K, BETA, MASKED, HAS_LEFT>(cur2, seed, nsrc, nseed, Y, X, d0, ucol_chk, Tn, vslot);
             RNNT_WD_STAMP(lb + 2, 1);
-            if (!dry) block_barrier();                         // (its lgkmcnt(0) also retires the in-place reloads)
+            if (!dry) {
+                // the value stores and the in-place reloads of the block (inline assembly, which no fence of the compiler's
+                // counts) have to be complete: one explicit wait, with a "memory" clobber that also keeps the compiler's own
+                // LDS accesses on their side of the barrier
+                ws::wait_lds();
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+            }
         };
         // head, steady state, tail: the predicated loop exists once (outer loop of two rounds, not unrolled)
 #pragma nounroll
@@ -383,7 +412,17 @@ __device__ __forceinline__ void sweep(const LatticeArgs& a, const Item it, const
             const int ps = p - 3;
             const bool ps_live = ps >= lo && ps < hi;
             RNNT_WD_STAMP(p, 5);
-            if constexpr (HAS_RIGHT) {
+            if constexpr (HAS_RIGHT && LOCAL) {
+                // the same values, straight into the right neighbour's seeds: diagonal d is seed (d + 1) mod K of its
+                // block (d + 1) / K (the neighbour reads block m's seeds two intervals from now: L_LOCAL)
+                if (lane < K && ps_live) {
+                    const int at = ps * K + lane + 1;
+                    float x = sm.vals[ps & (VSLOTS - 1)][lane][WAVE - 1];
+                    if constexpr (!BETA) x += sm.pairs[slot_st][lane][WAVE - 1].y;
+                    sm_right->mail_vals[(at / K) & (MIN_SLOTS - 1)][at % K] = x;
+                }
+            }
+            if constexpr (HAS_RIGHT && !LOCAL) {
                 // (a block that does not exist goes to the ring's pad granule, which nobody reads; eight lanes store --
                 // an agent-scope store is one fabric write per lane)
                 if (lane < K) {
@@ -411,6 +450,7 @@ __device__ __forceinline__ void sweep(const LatticeArgs& a, const Item it, const
             }
             if (ps_live) { row_st = r; slot_st = slot_st + 1 == PSLOTS ? 0 : slot_st + 1; }
             RNNT_WD_STAMP(p, 6);
+            if constexpr (HAS_RIGHT && LOCAL) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the seeds it wrote
             __builtin_amdgcn_s_barrier();                      // (its LDS reads are complete: the stores needed them)
         }
     }
@@ -434,20 +474,83 @@ __global__ void __launch_bounds__(3 * WAVE) k_lattice_wd(LatticeArgs a, const in
     it.n = s >> 1;
     it.dir = s & 1;
     const UttLens len = utt_lens<COMPACT>(a.xn, a.yn, it.n, a.T, a.U);
-    if (!COMPACT || len.ok) {   // (compact: an utterance with bad lengths has no plane of its own to sweep)
+    // (compact: an utterance with bad lengths has no plane of its own to sweep; beta_only: the alpha plane is not the
+    //  caller's to write -- run_warp_rnnt_compact with required_grad = false)
+    if ((!COMPACT || len.ok) && !(a.beta_only && !it.dir)) {
         const bool hl = it.cb > 0, hr = it.cb + 1 < (len.Un + WAVE - 1) / WAVE;
 #define RNNT_WD_SWEEP(B)                                                                    \
     do {                                                                                    \
-        if (hl) { if (hr) sweep<B, COMPACT, true, true>(a, it, len, nA, sm, &wg_bad);       \
-                  else sweep<B, COMPACT, true, false>(a, it, len, nA, sm, &wg_bad); }       \
-        else { if (hr) sweep<B, COMPACT, false, true>(a, it, len, nA, sm, &wg_bad);         \
-               else sweep<B, COMPACT, false, false>(a, it, len, nA, sm, &wg_bad); }         \
+        if (hl) { if (hr) sweep<B, COMPACT, true, true, false>(a, it, len, nA, sm, nullptr, &wg_bad, role);       \
+                  else sweep<B, COMPACT, true, false, false>(a, it, len, nA, sm, nullptr, &wg_bad, role); }       \
+        else { if (hr) sweep<B, COMPACT, false, true, false>(a, it, len, nA, sm, nullptr, &wg_bad, role);         \
+               else sweep<B, COMPACT, false, false, false>(a, it, len, nA, sm, nullptr, &wg_bad, role); }         \
     } while (0)
+        const int role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
         if (it.dir) RNNT_WD_SWEEP(true); else RNNT_WD_SWEEP(false);
 #undef RNNT_WD_SWEEP
     }
     __syncthreads();
     if (threadIdx.x == 0 && wg_bad && a.redo) atomicOr(&a.redo[2 * it.n + it.dir], wg_bad);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// k_lattice_wl: the same sweep with ALL column blocks of a sweep in one workgroup (three waves each), for lattices that
+// are too short, or batches that are too large, for a workgroup per column block to pay for its ring preparation, its
+// redo launch and its hand-over through L2 -- the place of lattice_ws.hip, with this file's wave roles (round 5).
+// Global interval g: column block idx runs its local time p = g - L_LOCAL * idx; every wave executes the same
+// g_end - g_begin barriers (idle ones in front of its block's first interval and behind its last).
+// ---------------------------------------------------------------------------------------------------------------
+template <bool COMPACT, int NA_MAX>
+__global__ void __launch_bounds__(3 * NA_MAX * WAVE) k_lattice_wl(const LatticeArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char wl_smem[];
+    Smem* const sms = reinterpret_cast<Smem*>(wl_smem);
+    // XCD-aware placement as in lattice_ws.hip: the alpha and the beta sweep of an utterance on one XCD (speed only)
+    const unsigned b = blockIdx.x, pairs_total = gridDim.x >> 1;
+    const unsigned grp = b >> 4, in = b & 15;
+    unsigned n, dir;
+    if ((grp << 3) + 8 <= pairs_total) { n = (grp << 3) + (in & 7); dir = in >> 3; }
+    else { const unsigned r = b - (grp << 4); n = (grp << 3) + (r >> 1); dir = r & 1; }   // tail group
+    if (a.beta_only && !dir) return;
+    if (a.redo && a.redo[2 * n + dir] == 0) return;   // launched behind a ring kernel: only the sweeps it flagged
+    const UttLens len = utt_lens<COMPACT>(a.xn, a.yn, (int)n, a.T, a.U);
+    if (COMPACT && !len.ok) return;                    // no plane of its own to sweep (uniform)
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int idx = w / 3, role = w - 3 * idx;
+    const int nA = blockDim.x / (3 * WAVE);
+    Item it;
+    it.n = (int)n; it.dir = (int)dir; it.cb = idx;
+    if (len.Un == 1) {                                 // no labels: one wave's prefix / suffix sums (uniform, no barrier)
+        if (w == 0) {
+            if (dir) sweep<true, COMPACT, false, false, true>(a, it, len, nA, sms[0], nullptr, nullptr, 0);
+            else sweep<false, COMPACT, false, false, true>(a, it, len, nA, sms[0], nullptr, nullptr, 0);
+        }
+        return;
+    }
+    const int Tn = len.Tn, Un = len.Un, ndiag = Tn + Un - 1;
+    const int nwa = (Un + WAVE - 1) / WAVE;            // column blocks with a live column
+    auto lo_of = [&](int i) { return WAVE * i / K; };
+    auto hi_of = [&](int i) { return (min(ndiag, Tn + WAVE * i + WAVE) + K - 1) / K; };
+    const int g_begin = lo_of(0) - DLOAD;
+    const int g_end = hi_of(nwa - 1) + 3 + L_LOCAL * (nwa - 1);
+    if (idx >= nwa) {                                  // a padded batch: this utterance is narrower than the launch
+        for (int g = g_begin; g < g_end; ++g) __builtin_amdgcn_s_barrier();
+        return;
+    }
+    const int g0 = lo_of(idx) - DLOAD + L_LOCAL * idx, g1 = hi_of(idx) + 3 + L_LOCAL * idx;
+    for (int g = g_begin; g < g0; ++g) __builtin_amdgcn_s_barrier();
+    const bool hl = idx > 0, hr = idx + 1 < nwa;
+    Smem& sm = sms[idx];
+    Smem* const smr = hr ? &sms[idx + 1] : nullptr;
+#define RNNT_WL_SWEEP(B)                                                                                     \
+    do {                                                                                                     \
+        if (hl) { if (hr) sweep<B, COMPACT, true, true, true>(a, it, len, nA, sm, smr, nullptr, role);       \
+                  else sweep<B, COMPACT, true, false, true>(a, it, len, nA, sm, smr, nullptr, role); }       \
+        else { if (hr) sweep<B, COMPACT, false, true, true>(a, it, len, nA, sm, smr, nullptr, role);         \
+               else sweep<B, COMPACT, false, false, true>(a, it, len, nA, sm, smr, nullptr, role); }         \
+    } while (0)
+    if (dir) RNNT_WL_SWEEP(true); else RNNT_WL_SWEEP(false);
+#undef RNNT_WL_SWEEP
+    for (int g = g1; g < g_end; ++g) __builtin_amdgcn_s_barrier();
 }
 
 }  // namespace wd
@@ -467,7 +570,7 @@ size_t wd_mail_bytes(int N, int T, int U) {
 hipError_t launch_lattice_wd(hipStream_t stream, const LatticeArgs& a0, int N) {
     if (N <= 0) return hipSuccess;
     const int nA = (a0.U + WAVE - 1) / WAVE;
-    if (a0.offs32) return hipErrorNotSupported;
+    if (a0.offs32 && (nA > 1 || a0.redo)) return hipErrorNotSupported;   // (32-bit offsets: the plain launch only)
 #ifdef RNNT_WD_STATS
     if (!a0.mail || !a0.redo || !a0.queue) return hipErrorNotSupported;
     const bool lone = false;
@@ -488,10 +591,60 @@ hipError_t launch_lattice_wd(hipStream_t stream, const LatticeArgs& a0, int N) {
         if (e != hipSuccess) return e;
     }
     const dim3 grid(2 * N * nA), block(3 * WAVE);
-    if (a.offs)
+    if (is_compact(a))
         wd::k_lattice_wd<true><<<grid, block, 0, stream>>>(a, nA);
     else
         wd::k_lattice_wd<false><<<grid, block, 0, stream>>>(a, nA);
+    return hipGetLastError();
+}
+
+// The single-workgroup form: one workgroup of 3 * ceil(U / 64) waves per sweep, nothing but the planes in global memory.
+// Padded or compact (either offset width); honours a.redo (only the flagged sweeps) and a.beta_only.
+// hipErrorNotSupported when the lattice is wider than the workgroup's LDS holds (wl_max_blocks() column blocks).
+int wl_max_blocks() {
+    // 2 column blocks (U <= 128) fit the 64 KiB every kernel gets; 5 (U <= 320) need the large-LDS opt-in, 148 KiB of
+    // the CU's 160.  RNNT_WL_MAX_BLOCKS = 0 ... 5 overrides (0: the kernel is never chosen), for A/B runs.
+    static const int v = [] {
+        const char* e = getenv("RNNT_WL_MAX_BLOCKS");
+        const int d = e ? atoi(e) : RNNT_WL_DEFAULT_MAX_BLOCKS;
+        return d < 0 ? 0 : (d > 5 ? 5 : d);
+    }();
+    return v;
+}
+
+hipError_t launch_lattice_wl(hipStream_t stream, const LatticeArgs& a, int N, int max_blocks) {
+    if (N <= 0) return hipSuccess;
+    const int nA = (a.U + WAVE - 1) / WAVE;
+    const size_t lds = sizeof(wd::Smem) * nA;
+    if (nA > max_blocks || nA > 5 || lds > 160 * 1024) return hipErrorNotSupported;
+    const dim3 grid(2 * N), block(3 * nA * WAVE);
+    const bool compact = is_compact(a);
+    const bool wide = nA > 2;                           // which instantiation (launch bounds: 384 / 960 threads)
+    const void* fn = wide ? (compact ? reinterpret_cast<const void*>(&wd::k_lattice_wl<true, 5>)
+                                     : reinterpret_cast<const void*>(&wd::k_lattice_wl<false, 5>))
+                          : (compact ? reinterpret_cast<const void*>(&wd::k_lattice_wl<true, 2>)
+                                     : reinterpret_cast<const void*>(&wd::k_lattice_wl<false, 2>));
+    if (lds > 64 * 1024) {
+        // > 64 KiB of dynamic LDS: an opt-in per kernel and device (idempotent and thread-safe; remembered per device)
+        static std::atomic<bool> attr_set[4][64];
+        int dev = -1;
+        if (hipGetDevice(&dev) != hipSuccess) dev = -1;
+        const int ci = (wide ? 2 : 0) + (compact ? 1 : 0);
+        const bool tracked = dev >= 0 && dev < 64;
+        if (!tracked || !attr_set[ci][dev].load(std::memory_order_acquire)) {
+            const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                     (int)(sizeof(wd::Smem) * (wide ? 5 : 2)));
+            if (e != hipSuccess) return e;
+            if (tracked) attr_set[ci][dev].store(true, std::memory_order_release);
+        }
+    }
+    if (wide) {
+        if (compact) wd::k_lattice_wl<true, 5><<<grid, block, lds, stream>>>(a);
+        else wd::k_lattice_wl<false, 5><<<grid, block, lds, stream>>>(a);
+    } else {
+        if (compact) wd::k_lattice_wl<true, 2><<<grid, block, lds, stream>>>(a);
+        else wd::k_lattice_wl<false, 2><<<grid, block, lds, stream>>>(a);
+    }
     return hipGetLastError();
 }
 

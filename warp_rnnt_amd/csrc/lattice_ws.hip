@@ -200,13 +200,18 @@ __device__ __forceinline__ void sweep(const LatticeArgs& a, const int n, Smem* s
         // Otherwise that column block -- the slowest link of the chain -- would run the predicated step for the
         // whole sweep.
         const bool full = (d0 >= min(wave_c + WAVE - 1, Un - 1)) && (d0 + K <= wave_c + Tn);
+        // (idx == 0: sweep column 0 is this wave's lane 0 -- the rim variant of the step, lattice_step.h)
+#define RNNT_WS_BLOCK(M_, R_)                                                                                         \
+    do {                                                                                                              \
+        if (idx == 0) compute_block<BETA, M_, R_, true>(cur, mvec, Y, X, d0, ucol_chk, Tn, vslot, mail_slot);         \
+        else compute_block<BETA, M_, R_, false>(cur, mvec, Y, X, d0, ucol_chk, Tn, vslot, mail_slot);                 \
+    } while (0)
         if (full) {
-            if (has_right) compute_block<BETA, false, true>(cur, mvec, Y, X, d0, ucol_chk, Tn, vslot, mail_slot);
-            else compute_block<BETA, false, false>(cur, mvec, Y, X, d0, ucol_chk, Tn, vslot, mail_slot);
+            if (has_right) RNNT_WS_BLOCK(false, true); else RNNT_WS_BLOCK(false, false);
         } else {
-            if (has_right) compute_block<BETA, true, true>(cur, mvec, Y, X, d0, ucol_chk, Tn, vslot, mail_slot);
-            else compute_block<BETA, true, false>(cur, mvec, Y, X, d0, ucol_chk, Tn, vslot, mail_slot);
+            if (has_right) RNNT_WS_BLOCK(true, true); else RNNT_WS_BLOCK(true, false);
         }
+#undef RNNT_WS_BLOCK
         block_barrier();
     };
     int g = 0;
@@ -238,6 +243,7 @@ __global__ void __launch_bounds__(2 * MAXA * WAVE) k_lattice_ws(const LatticeArg
     unsigned n, dir;
     if ((grp << 3) + 8 <= pairs_total) { n = (grp << 3) + (in & 7); dir = in >> 3; }
     else { const unsigned r = b - (grp << 4); n = (grp << 3) + (r >> 1); dir = r & 1; }   // tail group
+    if (a.beta_only && !dir) return;                  // (the alpha plane is not the caller's to write: compact shim)
     if (a.redo && a.redo[2 * n + dir] == 0) return;   // swept by the probability-domain kernel (uniform)
     if (dir)
         sweep<true, COMPACT>(a, n, smem);
@@ -261,17 +267,18 @@ hipError_t launch_lattice_ws(hipStream_t stream, const LatticeArgs& a, int N) {
     static std::atomic<bool> attr_set[2][64];
     int dev = -1;
     if (hipGetDevice(&dev) != hipSuccess) dev = -1;
-    const int ci = a.offs ? 1 : 0;
+    const bool compact = is_compact(a);       // 64-bit (native) or 32-bit (core.h shims) offsets: compact_base()
+    const int ci = compact ? 1 : 0;
     const bool tracked = dev >= 0 && dev < 64;
     if (!tracked || !attr_set[ci][dev].load(std::memory_order_acquire)) {
-        const void* fn = a.offs ? reinterpret_cast<const void*>(&ws::k_lattice_ws<true>)
+        const void* fn = compact ? reinterpret_cast<const void*>(&ws::k_lattice_ws<true>)
                                 : reinterpret_cast<const void*>(&ws::k_lattice_ws<false>);
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize,
                                            (int)(sizeof(ws::Smem) * ws::MAXA));
         if (e != hipSuccess) return e;
         if (tracked) attr_set[ci][dev].store(true, std::memory_order_release);
     }
-    if (a.offs)
+    if (compact)
         ws::k_lattice_ws<true><<<grid, block, lds, stream>>>(a);
     else
         ws::k_lattice_ws<false><<<grid, block, lds, stream>>>(a);

@@ -1456,17 +1456,25 @@ k_gather_compact_linear(const float* __restrict__ xs, const int* __restrict__ ys
                         const int* __restrict__ yn, const int64_t* __restrict__ offs,
                         const int* __restrict__ label_offs, float2* __restrict__ ws2, int64_t* __restrict__ loc,
                         int V, int blank, int N, int64_t STU) {
-    __shared__ int s_n0;
+    __shared__ int s_n0, s_n1;
     const int tid = threadIdx.x;
     const int64_t c0 = (int64_t)blockIdx.x * (256 * GCL_CELLS);
-    if (tid == 0) s_n0 = N;
+    // The utterances the chunk's first and last cell belong to: owner(c) = the first n with offs[n + 1] > c, by binary
+    // search (two lanes, <= 17 steps over an array that sits in L2; the first version had every workgroup scan all N + 1
+    // offsets).  Utterances without cells are never an owner; a refused batch -- every checked length 0 -- is dropped
+    // cell by cell below.  offs must be non-decreasing for the result to mean anything; for a malformed array the search
+    // still ends, on one well-defined utterance, and a cell outside that utterance's range is nobody's.
+    if (tid < 2) {
+        const int64_t c = tid == 0 ? c0 : min(c0 + 256 * GCL_CELLS, STU) - 1;
+        int lo = 0, hi = N;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (offs[mid + 1] > c) hi = mid; else lo = mid + 1;
+        }
+        if (tid == 0) s_n0 = lo; else s_n1 = lo;
+    }
     __syncthreads();
-    // the utterance the chunk starts in (utterances without cells never match; a refused batch -- every checked length 0
-    // -- is dropped below)
-    for (int n = tid; n < N; n += 256)
-        if (offs[n] <= c0 && c0 < offs[n + 1]) s_n0 = n;
-    __syncthreads();
-    const int n0 = s_n0;
+    const int n0 = s_n0, n1 = min(s_n1, N - 1);
     if (n0 >= N) return;
     float2 pair[GCL_CELLS];
     size_t dst[GCL_CELLS];
@@ -1480,9 +1488,12 @@ k_gather_compact_linear(const float* __restrict__ xs, const int* __restrict__ ys
         dst[k] = 0;
         labs[k] = blank;
         if (c >= STU) continue;
-        int n = n0;
-        while (n < N && c >= offs[n + 1]) ++n;
-        if (n >= N) continue;
+        int n = n0, hi = n1;                           // owner(c) within [n0, n1]: usually no step, or one
+        while (n < hi) {
+            const int mid = (n + hi) >> 1;
+            if (offs[mid + 1] > c) hi = mid; else n = mid + 1;
+        }
+        if (c >= offs[n + 1] || c < offs[n]) continue;  // (malformed offsets: nobody's cell)
         const int T = xn[n], U = yn[n] + 1;
         if (T < 1 || U < 1) continue;
         const unsigned local = (unsigned)(c - offs[n]);
@@ -1560,6 +1571,126 @@ hipError_t launch_gather_compact_rowmajor(hipStream_t stream, const float* xs, c
     if (tiles >= (1ull << 31) || N > 65535u) return hipErrorInvalidValue;
     k_gather_compact_rowmajor<<<dim3((unsigned)tiles, N), 256, 0, stream>>>(
         xs, ys, xn, yn, reinterpret_cast<float2*>(gather_xs), loc, mem_pref, label_pref, V, blank);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Layout turns of the staged form of run_warp_rnnt_compact (api.hip): the reference's compact tensors are ROW-MAJOR
+// packed pairs with 32-bit exclusive prefixes (no total: the last utterance's size closes the batch), the tuned kernels
+// want each utterance's own diagonal-major plane.  Same 32x32 LDS tiles as k_to_diagonal / k_from_diagonal, one grid over
+// (utterance, tile) with the utterance as the fastest index (tiles outside their utterance return at once).
+//   TO_DIAGONAL: src = row-major pairs -> dst = diagonal-major pairs
+//   otherwise:   (sa, sb) = the two channels as diagonal-major float planes -> dst = row-major pairs
+// ---------------------------------------------------------------------------------------------------------
+template <bool TO_DIAGONAL>
+__global__ void __launch_bounds__(256)
+k_turn_compact32(const float2* __restrict__ src, const float* __restrict__ sa, const float* __restrict__ sb,
+                 float2* __restrict__ dst, const unsigned* __restrict__ xn, const unsigned* __restrict__ yn,
+                 const unsigned* __restrict__ mem_pref, int tiles_u, unsigned N) {
+    __shared__ float2 tile[TD][TD + 1];
+    const unsigned rest = blockIdx.x / N;
+    const unsigned n = (blockIdx.x % N + rest) % N;
+    const int tu = rest % tiles_u, tt = rest / tiles_u;
+    const int T = (int)xn[n], U = (int)yn[n] + 1;
+    const int t0 = tt * TD, u0 = tu * TD;
+    if (T < 1 || U < 1 || t0 >= T || u0 >= U) return;          // (uniform)
+    const int ul = threadIdx.x & (TD - 1), tl0 = threadIdx.x >> 5;
+    const int u = u0 + ul;
+    const size_t nbase = (size_t)mem_pref[n];
+    // one pass by frames (lanes along u, row-major side), one by diagonals (diagonal-major side)
+    auto by_frames = [&](auto&& f) {
+#pragma unroll
+        for (int k = 0; k < TD / 8; ++k) {
+            const int tl = tl0 + 8 * k, t = t0 + tl;
+            if (t < T && u < U) f(tl, nbase + (size_t)t * U + u);
+        }
+    };
+    auto by_diagonals = [&](auto&& f) {
+#pragma unroll
+        for (int k = 0; k < (2 * TD) / 8; ++k) {
+            const int d = tl0 + 8 * k, tl = d - ul;
+            if (d < 2 * TD - 1 && tl >= 0 && tl < TD) {
+                const int t = t0 + tl;
+                if (t < T && u < U) {
+                    int r = t + u;
+                    r = r >= T ? r % T : r;
+                    f(tl, nbase + (size_t)r * U + u);
+                }
+            }
+        }
+    };
+    if constexpr (TO_DIAGONAL) {
+        by_frames([&](int tl, size_t at) { tile[tl][ul] = src[at]; });
+        __syncthreads();
+        by_diagonals([&](int tl, size_t at) { dst[at] = tile[tl][ul]; });
+    } else {
+        by_diagonals([&](int tl, size_t at) { tile[tl][ul] = make_float2(sa[at], sb[at]); });
+        __syncthreads();
+        by_frames([&](int tl, size_t at) { dst[at] = tile[tl][ul]; });
+    }
+}
+
+static hipError_t launch_turn_compact32(hipStream_t stream, bool to_diagonal, const float* src, const float* sa,
+                                        const float* sb, float* dst, const unsigned* xn, const unsigned* yn,
+                                        const unsigned* mem_pref, unsigned N, unsigned Tmax, unsigned Umax) {
+    if (N == 0 || Tmax == 0 || Umax == 0) return hipSuccess;
+    const unsigned tiles_t = (Tmax + TD - 1) / TD, tiles_u = (Umax + TD - 1) / TD;
+    const size_t nblk = (size_t)N * tiles_t * tiles_u;
+    if (nblk >= ((size_t)1 << 31)) return hipErrorInvalidValue;
+    if (to_diagonal)
+        k_turn_compact32<true><<<(unsigned)nblk, 256, 0, stream>>>(reinterpret_cast<const float2*>(src), nullptr, nullptr,
+                                                                   reinterpret_cast<float2*>(dst), xn, yn, mem_pref,
+                                                                   (int)tiles_u, N);
+    else
+        k_turn_compact32<false><<<(unsigned)nblk, 256, 0, stream>>>(nullptr, sa, sb, reinterpret_cast<float2*>(dst), xn,
+                                                                    yn, mem_pref, (int)tiles_u, N);
+    return hipGetLastError();
+}
+
+hipError_t launch_reskew_compact32(hipStream_t stream, const float* pairs_rowmajor, float* pairs_diagonal,
+                                   const unsigned* xn, const unsigned* yn, const unsigned* mem_pref, unsigned N,
+                                   unsigned Tmax, unsigned Umax) {
+    return launch_turn_compact32(stream, true, pairs_rowmajor, nullptr, nullptr, pairs_diagonal, xn, yn, mem_pref, N, Tmax,
+                                 Umax);
+}
+
+hipError_t launch_unskew_compact32(hipStream_t stream, const float* a_diagonal, const float* b_diagonal,
+                                   float* pairs_rowmajor, const unsigned* xn, const unsigned* yn, const unsigned* mem_pref,
+                                   unsigned N, unsigned Tmax, unsigned Umax) {
+    return launch_turn_compact32(stream, false, nullptr, a_diagonal, b_diagonal, pairs_rowmajor, xn, yn, mem_pref, N, Tmax,
+                                 Umax);
+}
+
+// (blank, label) pairs -> two planes over the cells of a compact batch whose total only the device knows (the last
+// prefix + the last utterance's size): the grid covers the bound, threads beyond the total return.
+__global__ void __launch_bounds__(256)
+k_split_pairs_compact32(const float2* __restrict__ src, float* __restrict__ a, float* __restrict__ b,
+                        const unsigned* __restrict__ xn, const unsigned* __restrict__ yn,
+                        const unsigned* __restrict__ mem_pref, unsigned N) {
+    const int tl = (int)xn[N - 1], ul = (int)yn[N - 1] + 1;
+    const size_t total = (size_t)mem_pref[N - 1] + ((tl >= 1 && ul >= 1) ? (size_t)tl * ul : 0);
+    // two cells per thread where the pointers allow 16-byte loads (the caller checks), the odd last cell alone
+    const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 2;
+    if (i + 1 < total) {
+        const float4 v = *reinterpret_cast<const float4*>(src + i);
+        *reinterpret_cast<float2*>(a + i) = make_float2(v.x, v.z);
+        *reinterpret_cast<float2*>(b + i) = make_float2(v.y, v.w);
+    } else if (i < total) {
+        const float2 v = src[i];
+        a[i] = v.x; b[i] = v.y;
+    }
+}
+
+hipError_t launch_split_pairs_compact32(hipStream_t stream, const float* pairs, float* a, float* b, const unsigned* xn,
+                                        const unsigned* yn, const unsigned* mem_pref, unsigned N, size_t cells_bound) {
+    if (N == 0 || cells_bound == 0) return hipSuccess;
+    const bool al = (reinterpret_cast<uintptr_t>(pairs) % 16 == 0) && (reinterpret_cast<uintptr_t>(a) % 8 == 0) &&
+                    (reinterpret_cast<uintptr_t>(b) % 8 == 0);
+    if (!al) return hipErrorInvalidValue;
+    const size_t nblk = (cells_bound / 2 + 1 + 255) / 256;
+    if (nblk >= ((size_t)1 << 31)) return hipErrorInvalidValue;
+    k_split_pairs_compact32<<<(unsigned)nblk, 256, 0, stream>>>(reinterpret_cast<const float2*>(pairs), a, b, xn, yn,
+                                                                mem_pref, N);
     return hipGetLastError();
 }
 

@@ -31,11 +31,26 @@ def _mismatch_policy():
     return os.environ.get("WARP_RNNT_AMD_CHECK_MISMATCH", "").lower()
 
 
-def loss(input, labels, xn, yn, input_kind, grads_kind, blank=0, fastemit_lambda=0.0, return_mismatch=False):
+LATTICE_ROUTES = {None: -1, "default": -1, "auto": 0, "logdomain": 1, "pd": 2}
+
+
+def _route(lattice):
+    try:
+        return LATTICE_ROUTES[lattice]
+    except KeyError:
+        raise ValueError(f"unknown lattice route {lattice!r}: expected one of 'auto', 'logdomain', 'pd' or None "
+                         "(None = the process-wide default, warp_rnnt_amd.set_lattice)") from None
+
+
+def loss(input, labels, xn, yn, input_kind, grads_kind, blank=0, fastemit_lambda=0.0, return_mismatch=False,
+         lattice=None):
     """costs (N,), grads (layout per grads_kind; None for GRADS_NONE) [, mismatch (N,) int32].
     Tensors must be validated by the caller (contiguous, fp32/int32, same GPU).  ``mismatch[n]`` is 1
     where the forward/backward consistency guard zeroed an utterance's gradients (or its lengths were
-    out of range)."""
+    out of range).  ``lattice``: the arithmetic of the sweeps for THIS call -- ``"auto"`` / ``"logdomain"`` (the
+    reference's) or ``"pd"`` (probability domain); ``None`` = the process-wide default of
+    :func:`warp_rnnt_amd.set_lattice`.  A per-call route reads and writes no shared state (``rnnt_amd_loss_ex``)."""
+    route = _route(lattice)
     L = _lib.load()
     N, T, U, V = input.shape
     dev = input.device
@@ -61,9 +76,9 @@ def loss(input, labels, xn, yn, input_kind, grads_kind, blank=0, fastemit_lambda
             raise RuntimeError("rnnt_loss status 5 (RNNT_STATUS_INVALID_ARGUMENT): unsupported sizes "
                                f"N={N} T={T} U={U}")
         ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
-        st = L.rnnt_amd_loss(_stream(dev), ws.data_ptr(), input_kind, input.data_ptr(), _ptr(labels),
-                             xn.data_ptr(), yn.data_ptr(), costs.data_ptr(), _ptr(grads), grads_kind,
-                             N, T, U, V, blank, float(fastemit_lambda))
+        st = L.rnnt_amd_loss_ex(_stream(dev), ws.data_ptr(), input_kind, input.data_ptr(), _ptr(labels),
+                                xn.data_ptr(), yn.data_ptr(), costs.data_ptr(), _ptr(grads), grads_kind,
+                                N, T, U, V, blank, float(fastemit_lambda), route)
         _check(st)
         policy = _mismatch_policy()
         if return_mismatch or policy:
@@ -140,7 +155,8 @@ def gather(log_probs, labels, blank=0):
     return out
 
 
-def loss_compact(xs, ys, xn, yn, blank=0, fastemit_lambda=0.0, required_grad=True, max_frames=None, max_labels=None):
+def loss_compact(xs, ys, xn, yn, blank=0, fastemit_lambda=0.0, required_grad=True, max_frames=None, max_labels=None,
+                 lattice=None):
     """Compact (ragged packed) layout: xs (STU,V), ys (sum yn,), xn/yn (N,).
     Returns (costs (N,), grads (STU,2) or None, loc (STU,) int64).
 
@@ -148,7 +164,11 @@ def loss_compact(xs, ys, xn, yn, blank=0, fastemit_lambda=0.0, required_grad=Tru
     reference's binding need the sums; the reference does four).  With ``max_frames >= max(xn)`` and ``max_labels >=
     max(yn)`` supplied by the caller: none -- offsets, maxima and checks stay on the device (``rnnt_amd_loss_compact_
     bounded``), the call can be captured into a HIP graph; a batch that does not fit the bounds or the tensors' sizes
-    comes back with NaN costs and zero gradients instead of an exception."""
+    comes back with NaN costs and zero gradients instead of an exception.  ``lattice``: as in :func:`loss` (a per-call
+    route is not available together with the bounds: that entry takes the process-wide default)."""
+    route = _route(lattice)
+    if route != -1 and max_frames is not None:
+        raise ValueError("lattice= cannot be combined with max_frames / max_labels")
     L = _lib.load()
     dev = xs.device
     N = xn.shape[0]
@@ -187,10 +207,10 @@ def loss_compact(xs, ys, xn, yn, blank=0, fastemit_lambda=0.0, required_grad=Tru
         if ws_bytes == 0:
             raise RuntimeError("rnnt_loss status 5 (RNNT_STATUS_INVALID_ARGUMENT): unsupported sizes")
         ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
-        st = L.rnnt_amd_loss_compact(_stream(dev), ws.data_ptr(), xs.data_ptr(), _ptr(ys), xn.data_ptr(),
-                                     yn.data_ptr(), offs.data_ptr(), loffs.data_ptr(), costs.data_ptr(),
-                                     _ptr(grads), loc.data_ptr(), N, STU, tmax, umax, V, blank,
-                                     float(fastemit_lambda))
+        st = L.rnnt_amd_loss_compact_ex(_stream(dev), ws.data_ptr(), xs.data_ptr(), _ptr(ys), xn.data_ptr(),
+                                        yn.data_ptr(), offs.data_ptr(), loffs.data_ptr(), costs.data_ptr(),
+                                        _ptr(grads), loc.data_ptr(), N, STU, tmax, umax, V, blank,
+                                        float(fastemit_lambda), route)
         _check(st)
     return costs, grads, loc
 
