@@ -60,6 +60,10 @@ VARIANTS = {
     "short_spin": ["-DRNNT_PD_SPIN_LIMIT=0", "-DRNNT_WD_SPIN_LIMIT=0"],
     # A/B (tools/lattice_routes.py): blocks of 16 diagonals per barrier in the column-block kernel instead of 8
     "wd_k16": ["-DRNNT_WD_K=16", "-DRNNT_WL_DEFAULT_MAX_BLOCKS=0"],
+    # A/B of k_lattice_wl's wave placement: six waves in column-block-major order / compute waves at raised priority
+    "wl_nopad": ["-DRNNT_WL_PAD=0"],
+    "wl_prio": ["-DRNNT_WL_PRIO=2"],
+    "wl_nopad_prio": ["-DRNNT_WL_PAD=0", "-DRNNT_WL_PRIO=2"],
 }
 
 

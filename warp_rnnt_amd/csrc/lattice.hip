@@ -352,7 +352,7 @@ __device__ __forceinline__ void sweep(const LatticeArgs& a, const int n, float (
                                                                      : &trash[w][lane];
                 // every lane live for the whole block?  (started: d0 >= last lane's column;
                 // not finished: d0+K-1 - first column < Tn; all 64 columns inside the lattice)
-                const bool full = (d0 >= wave_c + WAVE - 1) && (d0 + K <= wave_c + Tn) &&
+                const bool full = (d0 > wave_c + WAVE - 1) && (d0 + K <= wave_c + Tn) &&
                                   (wave_c + WAVE <= Un);
                 const bool has_right = w + 1 < nwa;   // someone consumes this wave's boundary column
                 if (full) {

@@ -290,41 +290,142 @@ __device__ __forceinline__ void beta_step(float& V, float& sd, const float cx, c
         (void)sd; (void)nseed_v;
     }
 }
+// The same diagonal in a HEAD block: lanes start inside it (their first live diagonal), none finishes.  What a lane
+// computes before its first live diagonal never reaches a result -- its values are not stored (the storer predicates),
+// what it hands right is read by lanes that are not live either, and its own state is replaced wholesale at the first
+// live diagonal, where the rim rule makes the value `emit` (which comes from the left neighbour's first live cell) and
+// Y, X follow from the value -- so the per-lane `live` selects of the general predicated step are not needed here, only
+// the rim select: one v_cndmask on a single-bit lane mask (bit = the lane whose first diagonal this is; 0 if none).
+template <int K_, bool SEEDED>
+__device__ __forceinline__ float alpha_head_step(float& Y, float& X, float& sd, const float cx, const float cy,
+                                                 const unsigned nseed_v, const float log2e, const unsigned long long col0_mask,
+                                                 const unsigned long long rim_mask) {
+    float t, e, val, u;
+    if constexpr (SEEDED) {
+        asm volatile("v_mov_b32_dpp %2, %1" RNNT_DPP "\n\t"          // emit: lane 0 keeps its seed
+                     "v_sub_f32 %3, %0, %2\n\t"
+                     "v_mul_f32_e64 %3, -|%3|, %9\n\t"
+                     "v_exp_f32 %4, %3\n\t"
+                     "v_max_f32 %5, %0, %2\n\t"
+                     RNNT_LSE_TAIL("%3", "%4", "%5", "%6")
+                     "v_add_f32 %5, %5, %4\n\t"
+                     "v_cndmask_b32_e64 %5, %5, %2, %12\n\t"         // rim: the lane's first live diagonal takes emit
+                     "ds_read_b32 %2, %10 offset:%11\n\t"            // the seed is spent: the next block's, in place
+                     "v_add_f32 %1, %5, %8\n\t"
+                     "v_add_f32 %0, %5, %7"
+                     : "+v"(Y), "+v"(X), "+v"(sd), "=&v"(t), "=&v"(e), "=&v"(val), "=&v"(u)
+                     : "v"(cx), "v"(cy), "s"(log2e), "v"(nseed_v), "n"(K_ * 4), "s"(rim_mask));
+    } else {
+        float em;
+        asm volatile("v_mov_b32_dpp %2, %1" RNNT_DPP " bound_ctrl:1\n\t"   // emit (lane 0: 0.0, unused)
+                     "v_sub_f32 %3, %0, %2\n\t"
+                     "v_mul_f32_e64 %3, -|%3|, %9\n\t"
+                     "v_exp_f32 %4, %3\n\t"
+                     "v_max_f32 %5, %0, %2\n\t"
+                     RNNT_LSE_TAIL("%3", "%4", "%5", "%6")
+                     "v_add_f32 %5, %5, %4\n\t"
+                     "v_cndmask_b32_e64 %5, %5, %2, %11\n\t"         // rim: first live diagonal takes emit
+                     "v_cndmask_b32_e64 %5, %5, %0, %10\n\t"         // rim: sweep column 0 (lane 0) takes skip
+                     "v_add_f32 %1, %5, %8\n\t"
+                     "v_add_f32 %0, %5, %7"
+                     : "+v"(Y), "+v"(X), "=&v"(em), "=&v"(t), "=&v"(e), "=&v"(val), "=&v"(u)
+                     : "v"(cx), "v"(cy), "s"(log2e), "s"(col0_mask), "s"(rim_mask));
+        (void)sd; (void)nseed_v;
+    }
+    return val;
+}
+template <int K_, bool SEEDED>
+__device__ __forceinline__ void beta_head_step(float& V, float& sd, const float cx, const float cy, const unsigned nseed_v,
+                                               const float log2e, const unsigned long long col0_mask,
+                                               const unsigned long long rim_mask) {
+    float sk, t, e, u;
+    if constexpr (SEEDED) {
+        asm volatile("v_add_f32 %2, %0, %6\n\t"                      // skip
+                     "v_mov_b32_dpp %1, %0" RNNT_DPP "\n\t"          // left
+                     "v_add_f32 %1, %1, %7\n\t"                      // emit
+                     "v_sub_f32 %3, %2, %1\n\t"
+                     "v_mul_f32_e64 %3, -|%3|, %8\n\t"
+                     "v_exp_f32 %4, %3\n\t"
+                     "v_max_f32 %2, %2, %1\n\t"
+                     RNNT_LSE_TAIL("%3", "%4", "%2", "%5")
+                     "v_add_f32 %0, %2, %4\n\t"
+                     "v_cndmask_b32_e64 %0, %0, %1, %11\n\t"         // rim: first live diagonal takes emit
+                     "ds_read_b32 %1, %9 offset:%10"                 // the seed is spent: the next block's, in place
+                     : "+v"(V), "+v"(sd), "=&v"(sk), "=&v"(t), "=&v"(e), "=&v"(u)
+                     : "v"(cx), "v"(cy), "s"(log2e), "v"(nseed_v), "n"(K_ * 4), "s"(rim_mask));
+    } else {
+        float em, mx;
+        asm volatile("v_add_f32 %1, %0, %7\n\t"                      // skip
+                     "v_add_f32_dpp %2, %0, %8" RNNT_DPP " bound_ctrl:1\n\t"   // emit (lane 0: 0 + label log-prob, unused)
+                     "v_sub_f32 %4, %1, %2\n\t"
+                     "v_mul_f32_e64 %4, -|%4|, %9\n\t"
+                     "v_exp_f32 %5, %4\n\t"
+                     "v_max_f32 %3, %1, %2\n\t"
+                     RNNT_LSE_TAIL("%4", "%5", "%3", "%6")
+                     "v_add_f32 %0, %3, %5\n\t"
+                     "v_cndmask_b32_e64 %0, %0, %2, %11\n\t"         // rim: first live diagonal takes emit
+                     "v_cndmask_b32_e64 %0, %0, %1, %10"             // rim: sweep column 0 (lane 0) takes skip
+                     : "+v"(V), "=&v"(sk), "=&v"(em), "=&v"(mx), "=&v"(t), "=&v"(e), "=&v"(u)
+                     : "v"(cx), "v"(cy), "s"(log2e), "s"(col0_mask), "s"(rim_mask));
+        (void)sd; (void)nseed_v;
+    }
+}
 #undef RNNT_LSE_TAIL
 #undef RNNT_DPP
 
 // steps [K_, KK) of a block, recursively (every LDS offset has to be an immediate)
-template <int KK, int K_, bool BETA, bool SEEDED>
+// HEAD: rim0 = the lane mask of the lane whose first live diagonal is the block's first (bit d0 - first sweep column of the
+// column block); step K_'s lane is K_ further up
+template <int KK, int K_, bool BETA, bool SEEDED, bool HEAD>
 __device__ __forceinline__ void fast_steps(f32x4 (&cur2)[KK / 2], float (&seed)[KK], const unsigned nsrc, const unsigned nseed_v,
                                            float& Y, float& X, float* vslot, const float log2e,
-                                           const unsigned long long col0_mask) {
+                                           const unsigned long long col0_mask, const unsigned long long rim0) {
     if constexpr (K_ < KK) {
         const float cx = (K_ & 1) ? cur2[K_ / 2].z : cur2[K_ / 2].x;
         const float cy = (K_ & 1) ? cur2[K_ / 2].w : cur2[K_ / 2].y;
+        // (a head block starts before the column block's last column does: first_off + K_ <= 63 -- lattice_wd.hip; one
+        //  scalar shift of the block's first mask per step)
+        const unsigned long long rim_mask = HEAD ? rim0 << K_ : 0ull;
         if constexpr (BETA) {
-            beta_step<K_, SEEDED>(X, seed[K_], cx, cy, nseed_v, log2e, col0_mask);
+            if constexpr (HEAD) beta_head_step<K_, SEEDED>(X, seed[K_], cx, cy, nseed_v, log2e, col0_mask, rim_mask);
+            else beta_step<K_, SEEDED>(X, seed[K_], cx, cy, nseed_v, log2e, col0_mask);
             vslot[K_ * WAVE] = X;       // (this store and the next step's first add sit between the value and its DPP read)
         } else {
-            vslot[K_ * WAVE] = alpha_step<K_, SEEDED>(Y, X, seed[K_], cx, cy, nseed_v, log2e, col0_mask);
+            if constexpr (HEAD)
+                vslot[K_ * WAVE] = alpha_head_step<K_, SEEDED>(Y, X, seed[K_], cx, cy, nseed_v, log2e, col0_mask, rim_mask);
+            else
+                vslot[K_ * WAVE] = alpha_step<K_, SEEDED>(Y, X, seed[K_], cx, cy, nseed_v, log2e, col0_mask);
         }                               // (alpha: the add of Y and this store sit between X and its DPP read)
         if constexpr ((K_ & 1) != 0) lds_reload_2rows<K_ - 1>(cur2[K_ / 2], nsrc);       // next block's pairs K_ - 1, K_
-        fast_steps<KK, K_ + 1, BETA, SEEDED>(cur2, seed, nsrc, nseed_v, Y, X, vslot, log2e, col0_mask);
+        fast_steps<KK, K_ + 1, BETA, SEEDED, HEAD>(cur2, seed, nsrc, nseed_v, Y, X, vslot, log2e, col0_mask, rim0);
     }
 }
 
 // nsrc / nseed: LDS byte addresses of the next block's pairs (this lane's column) and seeds; vslot: this block's slot of
 // the value ring, [KK][WAVE] + lane.  BETA keeps one state (X; Y is not used).
-template <int KK, bool BETA, bool MASKED, bool SEEDED>
+// MODE: what the lanes of the wave do inside the block
+enum BlockMode : int {
+    BLOCK_FULL = 0,      // every lane that owns a column is live throughout (hand-written steps)
+    BLOCK_HEAD = 1,      // lanes start inside it, none finishes (hand-written steps + the rim select)
+    BLOCK_MASKED = 2     // anything: lanes start and / or finish inside it (C++, per-lane predicates)
+};
+template <int KK, bool BETA, int MODE, bool SEEDED>
 __device__ __forceinline__ void compute_block_ip(f32x4 (&cur2)[KK / 2], float (&seed)[KK], const unsigned nsrc, const unsigned nseed,
                                                  float& Y, float& X, const int d0, const int ucol_chk, const int Tn,
-                                                 float* vslot) {
+                                                 float* vslot, const int first_off) {
     static_assert(KK == 8 || KK == 16, "blocks of 8 or 16 diagonals");
     // the seeds' LDS address in a VGPR the compiler cannot see through: it is wave-uniform, and left to itself the
     // compiler keeps it in an SGPR and copies it into a VGPR in front of EVERY reload (one v_mov per diagonal)
     unsigned nseed_v = nseed;
     if constexpr (SEEDED) asm volatile("" : "+v"(nseed_v));
-    if constexpr (!MASKED) {
-        fast_steps<KK, 0, BETA, SEEDED>(cur2, seed, nsrc, nseed_v, Y, X, vslot, 1.44269504088896340736f, 1ull);
+    if constexpr (MODE != BLOCK_MASKED) {
+        if constexpr (BETA && MODE == BLOCK_HEAD) {
+            // (one state register in the hand-written beta steps: lane 0 of the first column block starts from Y = 0, the
+            //  value it hands right before its first diagonal is read by nobody -- make the two one)
+            X = Y;
+        }
+        fast_steps<KK, 0, BETA, SEEDED, MODE == BLOCK_HEAD>(cur2, seed, nsrc, nseed_v, Y, X, vslot, 1.44269504088896340736f,
+                                                          1ull, 1ull << (first_off & 63));
         if constexpr (BETA) Y = X;
         return;
     }

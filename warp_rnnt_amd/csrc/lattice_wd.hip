@@ -83,6 +83,12 @@ constexpr int SPIN_LIMIT = RNNT_WD_SPIN_LIMIT;   // polls before a hand-over is 
 #ifndef RNNT_WD_LAG
 #define RNNT_WD_LAG 1
 #endif
+#ifndef RNNT_WL_PAD
+#define RNNT_WL_PAD 1          // two column blocks: eight waves, the compute waves alone on their SIMDs (k_lattice_wl)
+#endif
+#ifndef RNNT_WL_PRIO
+#define RNNT_WL_PRIO 0         // s_setprio of the compute waves of k_lattice_wl (0: none)
+#endif
 #ifndef RNNT_WL_DEFAULT_MAX_BLOCKS
 #define RNNT_WL_DEFAULT_MAX_BLOCKS 2
 #endif
@@ -326,15 +332,18 @@ __device__ __forceinline__ void sweep(const LatticeArgs& a, const Item it, const
         float X = NEG_INF;
         ws::f32x4 cur2[K / 2];                                 // pairs of diagonals 2j, 2j+1: (x, y) and (z, w)
         float seed[K];
-        // Blocks [lo, head_end) and [full_end, hi) have lanes that start or finish inside them (predicated variant),
-        // [head_end, full_end) have every lane that owns a column live throughout (lanes beyond the last column run
-        // the unpredicated code too: their values only travel right, their stores are dropped).
-        const int fb0 = max(lo, (min(wave_c + WAVE - 1, Un - 1) + K - 1) / K);   // d0 >= the last column's first diagonal
+        // Blocks [lo, head_end) have lanes that start inside them (head variant: the rim select only), [full_end, hi) lanes
+        // that finish (general predicated variant), [head_end, full_end) have every lane that owns a column live
+        // throughout (lanes beyond the last column run the unpredicated code too: their values only travel right, their
+        // stores are dropped).
+        // d0 > the last column's first diagonal: that diagonal itself is a rim cell (it takes `emit`, lattice_step.h), and
+        // what a lane holds before it is unspecified in the head variant -- it must not fall into a steady-state block
+        const int fb0 = max(lo, min(wave_c + WAVE - 1, Un - 1) / K + 1);
         const int fb1 = min(hi, (wave_c + Tn) / K);                              // d0 + K <= the first column's end
         int lb, head_end, full_end, tail_end;
         if (dry) {
-            // pseudo blocks: -2 in the predicated variant (a first column block goes straight into it at launch:
-            // warming it here would only delay the first barrier), -1 in the unpredicated one (needed K blocks later)
+            // pseudo blocks: -2 in the head variant (a first column block goes straight into it at launch: warming it
+            // here would only delay the first barrier), -1 in the steady-state one (needed 64 / K blocks later)
             lb = idx > 0 ? -2 : -1;
             head_end = -1; full_end = 0; tail_end = 0;
 #pragma unroll
@@ -355,13 +364,14 @@ __device__ __forceinline__ void sweep(const LatticeArgs& a, const Item it, const
             }
             block_barrier();
             lb = lo;
-            head_end = fb0 < fb1 ? fb0 : hi; full_end = fb0 < fb1 ? fb1 : head_end; tail_end = hi;
+            // (a lattice so short that lanes start and finish in the same blocks: everything in the general variant)
+            head_end = fb0 < fb1 ? fb0 : lo; full_end = fb0 < fb1 ? fb1 : lo; tail_end = hi;
         }
         int slot = 0;                                          // LDS slot of block lb's pairs (block lo = slot 0)
         const unsigned pairs0 = (unsigned)(size_t)(__attribute__((address_space(3))) const char*)&sm.pairs[0][0][pos];
         const unsigned seeds0 = (unsigned)(size_t)(__attribute__((address_space(3))) const char*)&sm.mail_vals[0][0];
-        auto one_block = [&](auto masked_c) {
-            constexpr bool MASKED = decltype(masked_c)::value;
+        auto one_block = [&](auto mode_c) {
+            constexpr int MODE = decltype(mode_c)::value;
             const int d0 = lb * K;
             RNNT_WD_STAMP(lb + 2, 0);
             slot = slot + 1 == PSLOTS ? 0 : slot + 1;          // now the NEXT block's slot: its pairs landed an interval ago
@@ -369,7 +379,7 @@ __device__ __forceinline__ void sweep(const LatticeArgs& a, const Item it, const
             const unsigned nseed = seeds0 + (unsigned)((lb + 1) & (MIN_SLOTS - 1)) * (K * 4);
             float* vslot = &sm.vals[lb & (VSLOTS - 1)][0][lane];
             // (no mailbox write on this wave: the storer rebuilds the boundary column from the values)
-            compute_block_ip<K, BETA, MASKED, HAS_LEFT>(cur2, seed, nsrc, nseed, Y, X, d0, ucol_chk, Tn, vslot);
+            compute_block_ip<K, BETA, MODE, HAS_LEFT>(cur2, seed, nsrc, nseed, Y, X, d0, ucol_chk, Tn, vslot, d0 - wave_c);
             RNNT_WD_STAMP(lb + 2, 1);
             if (!dry) {
                 // the value stores and the in-place reloads of the block (inline assembly, which no fence of the compiler's
@@ -380,17 +390,13 @@ __device__ __forceinline__ void sweep(const LatticeArgs& a, const Item it, const
                 asm volatile("" ::: "memory");
             }
         };
-        // head, steady state, tail: the predicated loop exists once (outer loop of two rounds, not unrolled)
+        // head (lanes start), steady state, tail (lanes finish; for short lattices: everything): each variant exists once
 #pragma nounroll
-        for (int round = 0; round < 2; ++round) {
-            const int mend = round == 0 ? head_end : tail_end;
+        for (; lb < head_end; ++lb) one_block(std::integral_constant<int, ws::BLOCK_HEAD>{});
 #pragma nounroll
-            for (; lb < mend; ++lb) one_block(std::true_type{});
-            if (round == 0) {
+        for (; lb < full_end; ++lb) one_block(std::integral_constant<int, ws::BLOCK_FULL>{});
 #pragma nounroll
-                for (; lb < full_end; ++lb) one_block(std::false_type{});
-            }
-        }
+        for (; lb < tail_end; ++lb) one_block(std::integral_constant<int, ws::BLOCK_MASKED>{});
         if (!dry) {
             for (int t = hi + 2; t < p1; ++t) block_barrier();
             if constexpr (!BETA) {
@@ -402,53 +408,81 @@ __device__ __forceinline__ void sweep(const LatticeArgs& a, const Item it, const
     }
 
     // ------------------------------ storer wave ------------------------------
+    // One interval of this wave must not take longer than one of the compute wave's (0.32 - 0.36 us since round 5: the
+    // barrier makes the slowest wave everybody's pace).  So: every LDS read of the interval is issued up front (one
+    // exposed LDS latency, not one per consumer), the steady-state blocks -- every lane that owns a column live, the K
+    // rows not wrapping around the plane -- store without per-lane predicates and with one scalar add per row, and only
+    // the blocks at either end of the column block's life (and the one block per sweep whose rows wrap) take the general
+    // form.
     {
         const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(out, 0, T * U * 4, RSRC_WORD3);
         const int voff_out = colvalid ? uc * 4 : OOB;
         const int rowb = U * 4;
         int row_st = row0;
         int slot_st = 0;                                       // LDS slot of block ps's pairs (block lo = slot 0)
+        // (the compute wave's fb0 / fb1: blocks [sfb0, sfb1) have no lane that starts or finishes inside them)
+        const int sfb0 = max(lo, min(wave_c + WAVE - 1, Un - 1) / K + 1);
+        const int sfb1 = min(hi, (wave_c + Tn) / K);
+        const int plane = lane < K ? lane : K - 1;             // the lane's diagonal of the boundary column
         for (int p = p0; p < p1; ++p) {
             const int ps = p - 3;
             const bool ps_live = ps >= lo && ps < hi;
             RNNT_WD_STAMP(p, 5);
-            if constexpr (HAS_RIGHT && LOCAL) {
-                // the same values, straight into the right neighbour's seeds: diagonal d is seed (d + 1) mod K of its
-                // block (d + 1) / K (the neighbour reads block m's seeds two intervals from now: L_LOCAL)
-                if (lane < K && ps_live) {
-                    const int at = ps * K + lane + 1;
-                    float x = sm.vals[ps & (VSLOTS - 1)][lane][WAVE - 1];
-                    if constexpr (!BETA) x += sm.pairs[slot_st][lane][WAVE - 1].y;
-                    sm_right->mail_vals[(at / K) & (MIN_SLOTS - 1)][at % K] = x;
-                }
+            // what the compute wave's lane 63 handed to its DPP shift after diagonal ps * K + plane: its value (beta), its
+            // value + the label log-prob of its cell (alpha) -- the same fp32 addition, the same bits.  (Where lane 63 is
+            // not live the result is meaningless and no live cell of the neighbour reads it.)
+            float x = 0.0f, xl = 0.0f;
+            if constexpr (HAS_RIGHT) {
+                x = sm.vals[ps & (VSLOTS - 1)][plane][WAVE - 1];
+                if constexpr (!BETA) xl = sm.pairs[slot_st][plane][WAVE - 1].y;   // (still in the ring: PSLOTS)
             }
-            if constexpr (HAS_RIGHT && !LOCAL) {
-                // (a block that does not exist goes to the ring's pad granule, which nobody reads; eight lanes store --
-                // an agent-scope store is one fabric write per lane)
-                if (lane < K) {
-                    const int d = ps * K + lane;
-                    const size_t at = ps_live ? (size_t)(d + 1) : pitch - 1;
-                    // what the compute wave's lane 63 handed to its DPP shift after diagonal d: its value (beta), its
-                    // value + the label log-prob of its cell (alpha) -- the same fp32 addition, the same bits.  (Where
-                    // lane 63 is not live the result is meaningless and no live cell of the neighbour reads it.)
-                    float x = sm.vals[ps & (VSLOTS - 1)][lane][WAVE - 1];
-                    if constexpr (!BETA) x += sm.pairs[slot_st][lane][WAVE - 1].y;   // (still in the ring: PSLOTS)
-                    const u64 g = ((u64)diag_tag(tag_out, d) << 32) | __builtin_bit_cast(unsigned, x);
-                    __hip_atomic_store(ring_out + at, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-            }
+            float v[K];
             const float* src = &sm.vals[ps & (VSLOTS - 1)][0][lane];
-            const int d0 = ps * K;
-            const int vo = ps_live ? voff_out : OOB;
-            int r = row_st;
 #pragma unroll
-            for (int k = 0; k < K; ++k) {
-                const bool live = (unsigned)(d0 + k - ucol_chk) < (unsigned)Tn;
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, src[k * WAVE]), rs_out, live ? vo : OOB,
-                                                      r * rowb, 0);
-                r = BETA ? (r == 0 ? T - 1 : r - 1) : (r + 1 == T ? 0 : r + 1);
+            for (int k = 0; k < K; ++k) v[k] = src[k * WAVE];
+            if constexpr (HAS_RIGHT) {
+                if constexpr (!BETA) x += xl;
+                if constexpr (LOCAL) {
+                    // straight into the right neighbour's seeds: diagonal d is seed (d + 1) mod K of its block (d + 1) / K
+                    // (the neighbour reads block m's seeds two intervals from now: L_LOCAL)
+                    if (lane < K && ps_live) {
+                        const int at = ps * K + lane + 1;
+                        sm_right->mail_vals[(at / K) & (MIN_SLOTS - 1)][at % K] = x;
+                    }
+                } else {
+                    // (a block that does not exist goes to the ring's pad granule, which nobody reads; K lanes store --
+                    // an agent-scope store is one fabric write per lane)
+                    if (lane < K) {
+                        const int d = ps * K + lane;
+                        const size_t at = ps_live ? (size_t)(d + 1) : pitch - 1;
+                        const u64 g = ((u64)diag_tag(tag_out, d) << 32) | __builtin_bit_cast(unsigned, x);
+                        __hip_atomic_store(ring_out + at, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
             }
-            if (ps_live) { row_st = r; slot_st = slot_st + 1 == PSLOTS ? 0 : slot_st + 1; }
+            const bool nowrap = BETA ? row_st >= K - 1 : row_st + K <= T;
+            if (ps >= sfb0 && ps < sfb1 && nowrap) {
+                int soff = row_st * rowb;
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v[k]), rs_out, voff_out, soff, 0);
+                    soff = BETA ? soff - rowb : soff + rowb;
+                }
+                row_st = BETA ? row_st - K : row_st + K;
+                if (BETA) { if (row_st < 0) row_st += T; } else { if (row_st >= T) row_st -= T; }
+                slot_st = slot_st + 1 == PSLOTS ? 0 : slot_st + 1;
+            } else {
+                const int d0 = ps * K;
+                const int vo = ps_live ? voff_out : OOB;
+                int r = row_st;
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    const bool live = (unsigned)(d0 + k - ucol_chk) < (unsigned)Tn;
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v[k]), rs_out, live ? vo : OOB, r * rowb, 0);
+                    r = BETA ? (r == 0 ? T - 1 : r - 1) : (r + 1 == T ? 0 : r + 1);
+                }
+                if (ps_live) { row_st = r; slot_st = slot_st + 1 == PSLOTS ? 0 : slot_st + 1; }
+            }
             RNNT_WD_STAMP(p, 6);
             if constexpr (HAS_RIGHT && LOCAL) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the seeds it wrote
             __builtin_amdgcn_s_barrier();                      // (its LDS reads are complete: the stores needed them)
@@ -501,7 +535,7 @@ __global__ void __launch_bounds__(3 * WAVE) k_lattice_wd(LatticeArgs a, const in
 // g_end - g_begin barriers (idle ones in front of its block's first interval and behind its last).
 // ---------------------------------------------------------------------------------------------------------------
 template <bool COMPACT, int NA_MAX>
-__global__ void __launch_bounds__(3 * NA_MAX * WAVE) k_lattice_wl(const LatticeArgs a) {
+__global__ void __launch_bounds__((NA_MAX == 2 ? 8 : 3 * NA_MAX) * WAVE) k_lattice_wl(const LatticeArgs a) {
     extern __shared__ __attribute__((aligned(16))) char wl_smem[];
     Smem* const sms = reinterpret_cast<Smem*>(wl_smem);
     // XCD-aware placement as in lattice_ws.hip: the alpha and the beta sweep of an utterance on one XCD (speed only)
@@ -514,9 +548,25 @@ __global__ void __launch_bounds__(3 * NA_MAX * WAVE) k_lattice_wl(const LatticeA
     if (a.redo && a.redo[2 * n + dir] == 0) return;   // launched behind a ring kernel: only the sweeps it flagged
     const UttLens len = utt_lens<COMPACT>(a.xn, a.yn, (int)n, a.T, a.U);
     if (COMPACT && !len.ok) return;                    // no plane of its own to sweep (uniform)
+    // Which wave does what.  A workgroup's waves go to the CU's four SIMDs in a fixed cyclic order, so waves w and w + 4
+    // share one.  A compute wave that shares its SIMD with a loader or a storer loses issue slots to it -- and the sweep
+    // runs at the pace of its slowest compute wave (two column blocks, six waves in column-block-major order: 57 ns per
+    // diagonal against 47 for a compute wave alone on its SIMD).  With two column blocks the workgroup is launched with
+    // eight waves: [compute 0, compute 1, loader 0, storer 0, -, -, loader 1, storer 1]; the two spare waves end at once
+    // (ended waves do not take part in barriers), the compute waves keep a SIMD each and the four helpers share the
+    // other two.  From three column blocks on the compute waves cannot all be alone: column-block-major order.
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int idx = w / 3, role = w - 3 * idx;
-    const int nA = blockDim.x / (3 * WAVE);
+    int idx, role, nA;
+    if (RNNT_WL_PAD && NA_MAX == 2 && blockDim.x == 8 * WAVE) {
+        if (w == 4 || w == 5) return;
+        nA = 2;
+        idx = (w == 1 || w >= 6) ? 1 : 0;
+        role = w < 2 ? 0 : ((w == 2 || w == 6) ? 1 : 2);
+    } else {
+        idx = w / 3; role = w - 3 * idx;
+        nA = blockDim.x / (3 * WAVE);
+    }
+    if (RNNT_WL_PRIO && role == 0) __builtin_amdgcn_s_setprio(RNNT_WL_PRIO);   // (A/B: the dependent chain first)
     Item it;
     it.n = (int)n; it.dir = (int)dir; it.cb = idx;
     if (len.Un == 1) {                                 // no labels: one wave's prefix / suffix sums (uniform, no barrier)
@@ -617,9 +667,9 @@ hipError_t launch_lattice_wl(hipStream_t stream, const LatticeArgs& a, int N, in
     const int nA = (a.U + WAVE - 1) / WAVE;
     const size_t lds = sizeof(wd::Smem) * nA;
     if (nA > max_blocks || nA > 5 || lds > 160 * 1024) return hipErrorNotSupported;
-    const dim3 grid(2 * N), block(3 * nA * WAVE);
+    const dim3 grid(2 * N), block((RNNT_WL_PAD && nA == 2 ? 8 : 3 * nA) * WAVE);
     const bool compact = is_compact(a);
-    const bool wide = nA > 2;                           // which instantiation (launch bounds: 384 / 960 threads)
+    const bool wide = nA > 2;                           // which instantiation (launch bounds: 512 / 960 threads)
     const void* fn = wide ? (compact ? reinterpret_cast<const void*>(&wd::k_lattice_wl<true, 5>)
                                      : reinterpret_cast<const void*>(&wd::k_lattice_wl<false, 5>))
                           : (compact ? reinterpret_cast<const void*>(&wd::k_lattice_wl<true, 2>)

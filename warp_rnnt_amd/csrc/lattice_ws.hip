@@ -199,7 +199,8 @@ __device__ __forceinline__ void sweep(const LatticeArgs& a, const int n, Smem* s
         // only travel to the right, to other such lanes, and the I/O wave drops their stores (voffset = OOB).
         // Otherwise that column block -- the slowest link of the chain -- would run the predicated step for the
         // whole sweep.
-        const bool full = (d0 >= min(wave_c + WAVE - 1, Un - 1)) && (d0 + K <= wave_c + Tn);
+        // (strictly behind the last column's first diagonal: that cell is on the rim -- it takes `emit`, not the lse)
+        const bool full = (d0 > min(wave_c + WAVE - 1, Un - 1)) && (d0 + K <= wave_c + Tn);
         // (idx == 0: sweep column 0 is this wave's lane 0 -- the rim variant of the step, lattice_step.h)
 #define RNNT_WS_BLOCK(M_, R_)                                                                                         \
     do {                                                                                                              \
