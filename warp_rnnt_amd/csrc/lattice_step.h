@@ -169,10 +169,11 @@ __device__ __forceinline__ void compute_block(const f32x2 (&cur)[K], const float
 //   * the pairs of two consecutive diagonals share a register quad (cur2[j] = {pair 2j, pair 2j+1}); once step 2j+1 has
 //     used it, ONE ds_read2st64_b64 refills it with the next block's two pairs (the rows of a block are 512 bytes apart:
 //     the instruction's stride);
-//   * SEEDED (the column block has a left neighbour): seed[k] holds the neighbour's boundary value for step k in
-//     every lane (a broadcast LDS read; only lane 0's copy matters: it is the `old` operand of the DPP shift, which
-//     lane 0 keeps).  The DPP consumes it, step k reloads it with the next block's value.  Not SEEDED = sweep column 0
-//     is this wave's lane 0 (COL0 above).
+//   * SEEDED (the column block has a left neighbour): the neighbour's boundary values for four consecutive steps share a
+//     register quad, every lane holding all four (broadcast LDS reads; only lane 0's copy matters: it is the `old`
+//     operand of the DPP shift, which lane 0 keeps).  The DPP of step k consumes component k mod 4 in place; once the
+//     fourth is spent ONE ds_read_b128 refills the quad with the next block's four.  Not SEEDED = sweep column 0 is this
+//     wave's lane 0 (COL0 above).
 // One buffer each = one copy of the block per variant in the instruction stream.
 // The reloads are inline assembly, so they are not counted by the compiler: the caller must not let a block start before
 // an `s_waitcnt lgkmcnt(0)` of its own (lattice_wd.hip: in front of every barrier of the compute wave).
@@ -195,11 +196,12 @@ __device__ __forceinline__ void compute_block(const f32x2 (&cur)[K], const float
 //     before the first use of anything an asm statement wrote -- hence whole steps, seed reload included.
 //     The one thing left to the compiler between two steps is the store of the value: an instruction it can see, which
 //     therefore counts as that wait state.)
-// Per diagonal: 14 VALU/LDS instructions + half a reload of pairs, against 17-18.
+// Per diagonal: 14 VALU/LDS instructions + half a reload of pairs + a quarter of a reload of seeds, against 17-18.
 // Hazards kept by construction (the compiler does not look inside): >= 2 instructions between the VALU write of the
 // value handed right and the DPP read of it (the store + one add), one instruction between v_exp_f32 / v_log_f32 and the
 // first ordinary VALU read of their result (v_max; v_add + v_sub).
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) float lds_float;   // (a pointer that can only be LDS: ds_write, never flat_store)
 
 template <int OFF0>
 __device__ __forceinline__ void lds_reload_2rows(f32x4& dst, const unsigned lds_byte_addr) {
@@ -210,6 +212,10 @@ template <int OFF>
 __device__ __forceinline__ void lds_reload_b32(float& dst, const unsigned lds_byte_addr) {
     asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(dst) : "v"(lds_byte_addr), "n"(OFF));
 }
+template <int OFF>
+__device__ __forceinline__ void lds_reload_b128(f32x4& dst, const unsigned lds_byte_addr) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(lds_byte_addr), "n"(OFF));
+}
 __device__ __forceinline__ void wait_lds() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
 #define RNNT_LSE_TAIL(T, E, MX, U)                                                                                      \
@@ -219,27 +225,33 @@ __device__ __forceinline__ void wait_lds() { asm volatile("s_waitcnt lgkmcnt(0)"
     "v_sub_f32 " E ", " E ", " U "\n\t"                                                                                  \
     "v_fmac_f32 " E ", 0x3f317218, " T "\n\t"
 #define RNNT_DPP " wave_shr:1 row_mask:0xf bank_mask:0xf"
+// the seed of step K_ is component K_ mod 4 of a register quad (a vector element can be an asm operand, not a reference)
+#define RNNT_WITH_SEED(C, STMT)                                                                                         \
+    do {                                                                                                                \
+        if constexpr ((C) == 0) { STMT(sd4.x); } else if constexpr ((C) == 1) { STMT(sd4.y); }                          \
+        else if constexpr ((C) == 2) { STMT(sd4.z); } else { STMT(sd4.w); }                                             \
+    } while (0)
 
 // One diagonal of a block every lane is live in; returns the cell's value (the caller stores it: a store the compiler can
 // see, between two statements -- see above).  K_ = the diagonal's index in the block (the seed's LDS offset).
 // alpha: Y = alpha + blank log-prob of the own previous cell, X = alpha + label log-prob (handed right).
 template <int K_, bool SEEDED>
-__device__ __forceinline__ float alpha_step(float& Y, float& X, float& sd, const float cx, const float cy,
-                                            const unsigned nseed_v, const float log2e, const unsigned long long col0_mask) {
+__device__ __forceinline__ float alpha_step(float& Y, float& X, f32x4& sd4, const float cx, const float cy, const float log2e, const unsigned long long col0_mask) {
     float t, e, val, u;
     if constexpr (SEEDED) {
-        asm volatile("v_mov_b32_dpp %2, %1" RNNT_DPP "\n\t"          // emit: lane i <- X of lane i-1, lane 0 keeps its seed
-                     "v_sub_f32 %3, %0, %2\n\t"                      // t = skip - emit
-                     "v_mul_f32_e64 %3, -|%3|, %9\n\t"
-                     "v_exp_f32 %4, %3\n\t"
-                     "v_max_f32 %5, %0, %2\n\t"
-                     "ds_read_b32 %2, %10 offset:%11\n\t"            // the seed is spent: the next block's, in place
-                     RNNT_LSE_TAIL("%3", "%4", "%5", "%6")
-                     "v_add_f32 %5, %5, %4\n\t"                      // val = max + l
-                     "v_add_f32 %1, %5, %8\n\t"                      // X = val + label log-prob
-                     "v_add_f32 %0, %5, %7"                           // Y = val + blank log-prob
-                     : "+v"(Y), "+v"(X), "+v"(sd), "=&v"(t), "=&v"(e), "=&v"(val), "=&v"(u)
-                     : "v"(cx), "v"(cy), "s"(log2e), "v"(nseed_v), "n"(K_ * 4));
+        #define RNNT_STEP_ASM(SD) asm volatile("v_mov_b32_dpp %2, %1" RNNT_DPP "\n\t"          /* emit: lane i <- X of lane i-1, lane 0 keeps its seed */ \
+                     "v_sub_f32 %3, %0, %2\n\t"                      /* t = skip - emit */ \
+                     "v_mul_f32_e64 %3, -|%3|, %9\n\t" \
+                     "v_exp_f32 %4, %3\n\t" \
+                     "v_max_f32 %5, %0, %2\n\t" \
+                     RNNT_LSE_TAIL("%3", "%4", "%5", "%6") \
+                     "v_add_f32 %5, %5, %4\n\t"                      /* val = max + l */ \
+                     "v_add_f32 %1, %5, %8\n\t"                      /* X = val + label log-prob */ \
+                     "v_add_f32 %0, %5, %7"                           /* Y = val + blank log-prob */ \
+                     : "+v"(Y), "+v"(X), "+v"(SD), "=&v"(t), "=&v"(e), "=&v"(val), "=&v"(u) \
+                     : "v"(cx), "v"(cy), "s"(log2e))
+        RNNT_WITH_SEED(K_ % 4, RNNT_STEP_ASM);
+        #undef RNNT_STEP_ASM
     } else {
         asm volatile("v_sub_f32_dpp %2, %1, %0" RNNT_DPP " bound_ctrl:1\n\t"   // t = emit - skip (lane 0: 0 - skip, unused)
                      "v_mul_f32_e64 %2, -|%2|, %8\n\t"
@@ -252,28 +264,28 @@ __device__ __forceinline__ float alpha_step(float& Y, float& X, float& sd, const
                      "v_add_f32 %0, %4, %6"
                      : "+v"(Y), "+v"(X), "=&v"(t), "=&v"(e), "=&v"(val), "=&v"(u)
                      : "v"(cx), "v"(cy), "s"(log2e), "s"(col0_mask));
-        (void)sd; (void)nseed_v;
+        (void)sd4;
     }
     return val;
 }
 // beta: V = beta of the own previous cell = what is handed right = the value.
 template <int K_, bool SEEDED>
-__device__ __forceinline__ void beta_step(float& V, float& sd, const float cx, const float cy, const unsigned nseed_v,
-                                          const float log2e, const unsigned long long col0_mask) {
+__device__ __forceinline__ void beta_step(float& V, f32x4& sd4, const float cx, const float cy, const float log2e, const unsigned long long col0_mask) {
     float sk, t, e, u;
     if constexpr (SEEDED) {
-        asm volatile("v_add_f32 %2, %0, %6\n\t"                      // skip = beta[t+1,u] + blank log-prob
-                     "v_mov_b32_dpp %1, %0" RNNT_DPP "\n\t"          // left
-                     "v_add_f32 %1, %1, %7\n\t"                      // emit = beta[t,u+1] + label log-prob
-                     "v_sub_f32 %3, %2, %1\n\t"
-                     "v_mul_f32_e64 %3, -|%3|, %8\n\t"
-                     "v_exp_f32 %4, %3\n\t"
-                     "v_max_f32 %2, %2, %1\n\t"
-                     "ds_read_b32 %1, %9 offset:%10\n\t"             // the seed is spent: the next block's, in place
-                     RNNT_LSE_TAIL("%3", "%4", "%2", "%5")
-                     "v_add_f32 %0, %2, %4"
-                     : "+v"(V), "+v"(sd), "=&v"(sk), "=&v"(t), "=&v"(e), "=&v"(u)
-                     : "v"(cx), "v"(cy), "s"(log2e), "v"(nseed_v), "n"(K_ * 4));
+        #define RNNT_STEP_ASM(SD) asm volatile("v_add_f32 %2, %0, %6\n\t"                      /* skip = beta[t+1,u] + blank log-prob */ \
+                     "v_mov_b32_dpp %1, %0" RNNT_DPP "\n\t"          /* left */ \
+                     "v_add_f32 %1, %1, %7\n\t"                      /* emit = beta[t,u+1] + label log-prob */ \
+                     "v_sub_f32 %3, %2, %1\n\t" \
+                     "v_mul_f32_e64 %3, -|%3|, %8\n\t" \
+                     "v_exp_f32 %4, %3\n\t" \
+                     "v_max_f32 %2, %2, %1\n\t" \
+                     RNNT_LSE_TAIL("%3", "%4", "%2", "%5") \
+                     "v_add_f32 %0, %2, %4" \
+                     : "+v"(V), "+v"(SD), "=&v"(sk), "=&v"(t), "=&v"(e), "=&v"(u) \
+                     : "v"(cx), "v"(cy), "s"(log2e))
+        RNNT_WITH_SEED(K_ % 4, RNNT_STEP_ASM);
+        #undef RNNT_STEP_ASM
     } else {
         float em;
         asm volatile("v_add_f32 %1, %0, %6\n\t"                      // skip
@@ -287,7 +299,7 @@ __device__ __forceinline__ void beta_step(float& V, float& sd, const float cx, c
                      "v_cndmask_b32_e64 %0, %0, %1, %9"              // sweep column 0 (lane 0): the rim takes skip
                      : "+v"(V), "=&v"(sk), "=&v"(em), "=&v"(t), "=&v"(e), "=&v"(u)
                      : "v"(cx), "v"(cy), "s"(log2e), "s"(col0_mask));
-        (void)sd; (void)nseed_v;
+        (void)sd4;
     }
 }
 // The same diagonal in a HEAD block: lanes start inside it (their first live diagonal), none finishes.  What a lane
@@ -297,24 +309,24 @@ __device__ __forceinline__ void beta_step(float& V, float& sd, const float cx, c
 // Y, X follow from the value -- so the per-lane `live` selects of the general predicated step are not needed here, only
 // the rim select: one v_cndmask on a single-bit lane mask (bit = the lane whose first diagonal this is; 0 if none).
 template <int K_, bool SEEDED>
-__device__ __forceinline__ float alpha_head_step(float& Y, float& X, float& sd, const float cx, const float cy,
-                                                 const unsigned nseed_v, const float log2e, const unsigned long long col0_mask,
+__device__ __forceinline__ float alpha_head_step(float& Y, float& X, f32x4& sd4, const float cx, const float cy, const float log2e, const unsigned long long col0_mask,
                                                  const unsigned long long rim_mask) {
     float t, e, val, u;
     if constexpr (SEEDED) {
-        asm volatile("v_mov_b32_dpp %2, %1" RNNT_DPP "\n\t"          // emit: lane 0 keeps its seed
-                     "v_sub_f32 %3, %0, %2\n\t"
-                     "v_mul_f32_e64 %3, -|%3|, %9\n\t"
-                     "v_exp_f32 %4, %3\n\t"
-                     "v_max_f32 %5, %0, %2\n\t"
-                     RNNT_LSE_TAIL("%3", "%4", "%5", "%6")
-                     "v_add_f32 %5, %5, %4\n\t"
-                     "v_cndmask_b32_e64 %5, %5, %2, %12\n\t"         // rim: the lane's first live diagonal takes emit
-                     "ds_read_b32 %2, %10 offset:%11\n\t"            // the seed is spent: the next block's, in place
-                     "v_add_f32 %1, %5, %8\n\t"
-                     "v_add_f32 %0, %5, %7"
-                     : "+v"(Y), "+v"(X), "+v"(sd), "=&v"(t), "=&v"(e), "=&v"(val), "=&v"(u)
-                     : "v"(cx), "v"(cy), "s"(log2e), "v"(nseed_v), "n"(K_ * 4), "s"(rim_mask));
+        #define RNNT_STEP_ASM(SD) asm volatile("v_mov_b32_dpp %2, %1" RNNT_DPP "\n\t"          /* emit: lane 0 keeps its seed */ \
+                     "v_sub_f32 %3, %0, %2\n\t" \
+                     "v_mul_f32_e64 %3, -|%3|, %9\n\t" \
+                     "v_exp_f32 %4, %3\n\t" \
+                     "v_max_f32 %5, %0, %2\n\t" \
+                     RNNT_LSE_TAIL("%3", "%4", "%5", "%6") \
+                     "v_add_f32 %5, %5, %4\n\t" \
+                     "v_cndmask_b32_e64 %5, %5, %2, %10\n\t"         /* rim: the lane's first live diagonal takes emit */ \
+                     "v_add_f32 %1, %5, %8\n\t" \
+                     "v_add_f32 %0, %5, %7" \
+                     : "+v"(Y), "+v"(X), "+v"(SD), "=&v"(t), "=&v"(e), "=&v"(val), "=&v"(u) \
+                     : "v"(cx), "v"(cy), "s"(log2e), "s"(rim_mask))
+        RNNT_WITH_SEED(K_ % 4, RNNT_STEP_ASM);
+        #undef RNNT_STEP_ASM
     } else {
         float em;
         asm volatile("v_mov_b32_dpp %2, %1" RNNT_DPP " bound_ctrl:1\n\t"   // emit (lane 0: 0.0, unused)
@@ -330,29 +342,29 @@ __device__ __forceinline__ float alpha_head_step(float& Y, float& X, float& sd, 
                      "v_add_f32 %0, %5, %7"
                      : "+v"(Y), "+v"(X), "=&v"(em), "=&v"(t), "=&v"(e), "=&v"(val), "=&v"(u)
                      : "v"(cx), "v"(cy), "s"(log2e), "s"(col0_mask), "s"(rim_mask));
-        (void)sd; (void)nseed_v;
+        (void)sd4;
     }
     return val;
 }
 template <int K_, bool SEEDED>
-__device__ __forceinline__ void beta_head_step(float& V, float& sd, const float cx, const float cy, const unsigned nseed_v,
-                                               const float log2e, const unsigned long long col0_mask,
+__device__ __forceinline__ void beta_head_step(float& V, f32x4& sd4, const float cx, const float cy, const float log2e, const unsigned long long col0_mask,
                                                const unsigned long long rim_mask) {
     float sk, t, e, u;
     if constexpr (SEEDED) {
-        asm volatile("v_add_f32 %2, %0, %6\n\t"                      // skip
-                     "v_mov_b32_dpp %1, %0" RNNT_DPP "\n\t"          // left
-                     "v_add_f32 %1, %1, %7\n\t"                      // emit
-                     "v_sub_f32 %3, %2, %1\n\t"
-                     "v_mul_f32_e64 %3, -|%3|, %8\n\t"
-                     "v_exp_f32 %4, %3\n\t"
-                     "v_max_f32 %2, %2, %1\n\t"
-                     RNNT_LSE_TAIL("%3", "%4", "%2", "%5")
-                     "v_add_f32 %0, %2, %4\n\t"
-                     "v_cndmask_b32_e64 %0, %0, %1, %11\n\t"         // rim: first live diagonal takes emit
-                     "ds_read_b32 %1, %9 offset:%10"                 // the seed is spent: the next block's, in place
-                     : "+v"(V), "+v"(sd), "=&v"(sk), "=&v"(t), "=&v"(e), "=&v"(u)
-                     : "v"(cx), "v"(cy), "s"(log2e), "v"(nseed_v), "n"(K_ * 4), "s"(rim_mask));
+        #define RNNT_STEP_ASM(SD) asm volatile("v_add_f32 %2, %0, %6\n\t"                      /* skip */ \
+                     "v_mov_b32_dpp %1, %0" RNNT_DPP "\n\t"          /* left */ \
+                     "v_add_f32 %1, %1, %7\n\t"                      /* emit */ \
+                     "v_sub_f32 %3, %2, %1\n\t" \
+                     "v_mul_f32_e64 %3, -|%3|, %8\n\t" \
+                     "v_exp_f32 %4, %3\n\t" \
+                     "v_max_f32 %2, %2, %1\n\t" \
+                     RNNT_LSE_TAIL("%3", "%4", "%2", "%5") \
+                     "v_add_f32 %0, %2, %4\n\t" \
+                     "v_cndmask_b32_e64 %0, %0, %1, %9"              /* rim: first live diagonal takes emit */ \
+                     : "+v"(V), "+v"(SD), "=&v"(sk), "=&v"(t), "=&v"(e), "=&v"(u) \
+                     : "v"(cx), "v"(cy), "s"(log2e), "s"(rim_mask))
+        RNNT_WITH_SEED(K_ % 4, RNNT_STEP_ASM);
+        #undef RNNT_STEP_ASM
     } else {
         float em, mx;
         asm volatile("v_add_f32 %1, %0, %7\n\t"                      // skip
@@ -367,9 +379,10 @@ __device__ __forceinline__ void beta_head_step(float& V, float& sd, const float 
                      "v_cndmask_b32_e64 %0, %0, %1, %10"             // rim: sweep column 0 (lane 0) takes skip
                      : "+v"(V), "=&v"(sk), "=&v"(em), "=&v"(mx), "=&v"(t), "=&v"(e), "=&v"(u)
                      : "v"(cx), "v"(cy), "s"(log2e), "s"(col0_mask), "s"(rim_mask));
-        (void)sd; (void)nseed_v;
+        (void)sd4;
     }
 }
+#undef RNNT_WITH_SEED
 #undef RNNT_LSE_TAIL
 #undef RNNT_DPP
 
@@ -377,8 +390,8 @@ __device__ __forceinline__ void beta_head_step(float& V, float& sd, const float 
 // HEAD: rim0 = the lane mask of the lane whose first live diagonal is the block's first (bit d0 - first sweep column of the
 // column block); step K_'s lane is K_ further up
 template <int KK, int K_, bool BETA, bool SEEDED, bool HEAD>
-__device__ __forceinline__ void fast_steps(f32x4 (&cur2)[KK / 2], float (&seed)[KK], const unsigned nsrc, const unsigned nseed_v,
-                                           float& Y, float& X, float* vslot, const float log2e,
+__device__ __forceinline__ void fast_steps(f32x4 (&cur2)[KK / 2], f32x4 (&seed4)[KK / 4], const unsigned nsrc, const unsigned nseed_v,
+                                           float& Y, float& X, lds_float* vslot, const float log2e,
                                            const unsigned long long col0_mask, const unsigned long long rim0) {
     if constexpr (K_ < KK) {
         const float cx = (K_ & 1) ? cur2[K_ / 2].z : cur2[K_ / 2].x;
@@ -386,18 +399,26 @@ __device__ __forceinline__ void fast_steps(f32x4 (&cur2)[KK / 2], float (&seed)[
         // (a head block starts before the column block's last column does: first_off + K_ <= 63 -- lattice_wd.hip; one
         //  scalar shift of the block's first mask per step)
         const unsigned long long rim_mask = HEAD ? rim0 << K_ : 0ull;
+        // (the seed of step K_: a component of a register quad -- the DPP shift works on it in place; four steps on, one
+        //  ds_read_b128 refills the quad with the next block's four)
+        f32x4 unused_seed = {0.0f, 0.0f, 0.0f, 0.0f};
+        f32x4& sd4 = SEEDED ? seed4[K_ / 4] : unused_seed;
         if constexpr (BETA) {
-            if constexpr (HEAD) beta_head_step<K_, SEEDED>(X, seed[K_], cx, cy, nseed_v, log2e, col0_mask, rim_mask);
-            else beta_step<K_, SEEDED>(X, seed[K_], cx, cy, nseed_v, log2e, col0_mask);
+            if constexpr (HEAD) beta_head_step<K_, SEEDED>(X, sd4, cx, cy, log2e, col0_mask, rim_mask);
+            else beta_step<K_, SEEDED>(X, sd4, cx, cy, log2e, col0_mask);
             vslot[K_ * WAVE] = X;       // (this store and the next step's first add sit between the value and its DPP read)
         } else {
-            if constexpr (HEAD)
-                vslot[K_ * WAVE] = alpha_head_step<K_, SEEDED>(Y, X, seed[K_], cx, cy, nseed_v, log2e, col0_mask, rim_mask);
-            else
-                vslot[K_ * WAVE] = alpha_step<K_, SEEDED>(Y, X, seed[K_], cx, cy, nseed_v, log2e, col0_mask);
-        }                               // (alpha: the add of Y and this store sit between X and its DPP read)
+            float val;
+            if constexpr (HEAD) val = alpha_head_step<K_, SEEDED>(Y, X, sd4, cx, cy, log2e, col0_mask, rim_mask);
+            else val = alpha_step<K_, SEEDED>(Y, X, sd4, cx, cy, log2e, col0_mask);
+            vslot[K_ * WAVE] = val;     // (alpha: the add of Y and this store sit between X and its DPP read)
+        }
+        // (the store above is what separates the step's statement from the reloads: the compiler pads a wait state in
+        //  front of a statement that redefines a register the previous statement wrote, unless an instruction of its own
+        //  sits between them)
+        if constexpr (SEEDED && K_ % 4 == 3) lds_reload_b128<(K_ - 3) * 4>(seed4[K_ / 4], nseed_v);   // next block's seeds
         if constexpr ((K_ & 1) != 0) lds_reload_2rows<K_ - 1>(cur2[K_ / 2], nsrc);       // next block's pairs K_ - 1, K_
-        fast_steps<KK, K_ + 1, BETA, SEEDED, HEAD>(cur2, seed, nsrc, nseed_v, Y, X, vslot, log2e, col0_mask, rim0);
+        fast_steps<KK, K_ + 1, BETA, SEEDED, HEAD>(cur2, seed4, nsrc, nseed_v, Y, X, vslot, log2e, col0_mask, rim0);
     }
 }
 
@@ -410,9 +431,9 @@ enum BlockMode : int {
     BLOCK_MASKED = 2     // anything: lanes start and / or finish inside it (C++, per-lane predicates)
 };
 template <int KK, bool BETA, int MODE, bool SEEDED>
-__device__ __forceinline__ void compute_block_ip(f32x4 (&cur2)[KK / 2], float (&seed)[KK], const unsigned nsrc, const unsigned nseed,
+__device__ __forceinline__ void compute_block_ip(f32x4 (&cur2)[KK / 2], f32x4 (&seed4)[KK / 4], const unsigned nsrc, const unsigned nseed,
                                                  float& Y, float& X, const int d0, const int ucol_chk, const int Tn,
-                                                 float* vslot, const int first_off) {
+                                                 lds_float* vslot, const int first_off) {
     static_assert(KK == 8 || KK == 16, "blocks of 8 or 16 diagonals");
     // the seeds' LDS address in a VGPR the compiler cannot see through: it is wave-uniform, and left to itself the
     // compiler keeps it in an SGPR and copies it into a VGPR in front of EVERY reload (one v_mov per diagonal)
@@ -424,7 +445,7 @@ __device__ __forceinline__ void compute_block_ip(f32x4 (&cur2)[KK / 2], float (&
             //  value it hands right before its first diagonal is read by nobody -- make the two one)
             X = Y;
         }
-        fast_steps<KK, 0, BETA, SEEDED, MODE == BLOCK_HEAD>(cur2, seed, nsrc, nseed_v, Y, X, vslot, 1.44269504088896340736f,
+        fast_steps<KK, 0, BETA, SEEDED, MODE == BLOCK_HEAD>(cur2, seed4, nsrc, nseed_v, Y, X, vslot, 1.44269504088896340736f,
                                                           1ull, 1ull << (first_off & 63));
         if constexpr (BETA) Y = X;
         return;
@@ -450,7 +471,7 @@ __device__ __forceinline__ void compute_block_ip(f32x4 (&cur2)[KK / 2], float (&
             skip = Y;
         }
         float left;
-        if constexpr (SEEDED) left = wave_shr1(seed[k], X); else left = wave_shr1_z(X);   // chain
+        if constexpr (SEEDED) left = wave_shr1(seed4[k / 4][k % 4], X); else left = wave_shr1_z(X);   // chain
         RNNT_PIN();
         if constexpr (BETA) {
             emit = left + cy;                                                          // chain
@@ -483,17 +504,13 @@ __device__ __forceinline__ void compute_block_ip(f32x4 (&cur2)[KK / 2], float (&
         val = rim ? emit : val;                                                        // rim: first live diagonal
         RNNT_PIN();
         if constexpr (SEEDED) {
-            switch (k) {   // next block's boundary value k (the seed's register is `emit` up to here)
-                case 0: lds_reload_b32<0>(seed[k], nseed_v); break;   case 1: lds_reload_b32<4>(seed[k], nseed_v); break;
-                case 2: lds_reload_b32<8>(seed[k], nseed_v); break;   case 3: lds_reload_b32<12>(seed[k], nseed_v); break;
-                case 4: lds_reload_b32<16>(seed[k], nseed_v); break;  case 5: lds_reload_b32<20>(seed[k], nseed_v); break;
-                case 6: lds_reload_b32<24>(seed[k], nseed_v); break;  case 7: lds_reload_b32<28>(seed[k], nseed_v); break;
-                case 8: lds_reload_b32<32>(seed[k], nseed_v); break;  case 9: lds_reload_b32<36>(seed[k], nseed_v); break;
-                case 10: lds_reload_b32<40>(seed[k], nseed_v); break; case 11: lds_reload_b32<44>(seed[k], nseed_v); break;
-                case 12: lds_reload_b32<48>(seed[k], nseed_v); break; case 13: lds_reload_b32<52>(seed[k], nseed_v); break;
-                case 14: lds_reload_b32<56>(seed[k], nseed_v); break; default: lds_reload_b32<60>(seed[k], nseed_v); break;
+            if (k % 4 == 3) {   // next block's boundary values k - 3 ... k (their registers are spent)
+                switch (k) {
+                    case 3: lds_reload_b128<0>(seed4[k / 4], nseed_v); break;   case 7: lds_reload_b128<16>(seed4[k / 4], nseed_v); break;
+                    case 11: lds_reload_b128<32>(seed4[k / 4], nseed_v); break; default: lds_reload_b128<48>(seed4[k / 4], nseed_v); break;
+                }
+                RNNT_PIN();
             }
-            RNNT_PIN();
         }
         if constexpr (!SEEDED) { val = col0 ? skip : val; RNNT_PIN(); }                // rim: sweep column 0
         float Yn, Xn;

@@ -331,7 +331,7 @@ __device__ __forceinline__ void sweep(const LatticeArgs& a, const Item it, const
         float Y = (ucol == 0) ? 0.0f : NEG_INF;
         float X = NEG_INF;
         ws::f32x4 cur2[K / 2];                                 // pairs of diagonals 2j, 2j+1: (x, y) and (z, w)
-        float seed[K];
+        ws::f32x4 seed4[K / 4];                                // the neighbour's boundary values of diagonals 4j ... 4j+3
         // Blocks [lo, head_end) have lanes that start inside them (head variant: the rim select only), [full_end, hi) lanes
         // that finish (general predicated variant), [head_end, full_end) have every lane that owns a column live
         // throughout (lanes beyond the last column run the unpredicated code too: their values only travel right, their
@@ -347,7 +347,7 @@ __device__ __forceinline__ void sweep(const LatticeArgs& a, const Item it, const
             lb = idx > 0 ? -2 : -1;
             head_end = -1; full_end = 0; tail_end = 0;
 #pragma unroll
-            for (int k = 0; k < K; ++k) seed[k] = -3.0f;
+            for (int j = 0; j < K / 4; ++j) seed4[j] = ws::f32x4{-3.0f, -3.0f, -3.0f, -3.0f};
 #pragma unroll
             for (int j = 0; j < K / 2; ++j) cur2[j] = ws::f32x4{-1.0f, -2.0f, -1.0f, -2.0f};
         } else {
@@ -356,7 +356,10 @@ __device__ __forceinline__ void sweep(const LatticeArgs& a, const Item it, const
             for (int t = p0; t < lo + 1; ++t) block_barrier();
             const f32x2* src = &sm.pairs[0][0][pos];
 #pragma unroll
-            for (int k = 0; k < K; ++k) seed[k] = HAS_LEFT ? sm.mail_vals[lo & (MIN_SLOTS - 1)][k] : NEG_INF;
+            for (int j = 0; j < K / 4; ++j) {
+                const float* mv = &sm.mail_vals[lo & (MIN_SLOTS - 1)][4 * j];
+                seed4[j] = HAS_LEFT ? ws::f32x4{mv[0], mv[1], mv[2], mv[3]} : ws::f32x4{NEG_INF, NEG_INF, NEG_INF, NEG_INF};
+            }
 #pragma unroll
             for (int j = 0; j < K / 2; ++j) {
                 const f32x2 a0 = src[(2 * j) * WAVE], a1 = src[(2 * j + 1) * WAVE];
@@ -370,17 +373,29 @@ __device__ __forceinline__ void sweep(const LatticeArgs& a, const Item it, const
         int slot = 0;                                          // LDS slot of block lb's pairs (block lo = slot 0)
         const unsigned pairs0 = (unsigned)(size_t)(__attribute__((address_space(3))) const char*)&sm.pairs[0][0][pos];
         const unsigned seeds0 = (unsigned)(size_t)(__attribute__((address_space(3))) const char*)&sm.mail_vals[0][0];
+        // what block lb needs besides its registers: the LDS addresses of the NEXT block's pairs and seeds (reloaded in
+        // place as it goes) and its own slot of the value ring.  Worked out for the first block here and for every
+        // following one at the END of its predecessor, in front of the wait for that block's last reloads -- arithmetic
+        // that needs nothing from LDS, in the shadow of an LDS round trip the wave would otherwise sit out.
+        unsigned nsrc = 0, nseed = 0;
+        ws::lds_float* vslot = nullptr;
+        auto prepare_block = [&]() {
+            slot = slot + 1 == PSLOTS ? 0 : slot + 1;          // the NEXT block's slot: its pairs landed an interval ago
+            nsrc = pairs0 + (unsigned)slot * (unsigned)(K * WAVE * 8);
+            nseed = seeds0 + (unsigned)((lb + 1) & (MIN_SLOTS - 1)) * (K * 4);
+            vslot = (ws::lds_float*)&sm.vals[lb & (VSLOTS - 1)][0][lane];
+        };
+        prepare_block();
         auto one_block = [&](auto mode_c) {
             constexpr int MODE = decltype(mode_c)::value;
             const int d0 = lb * K;
             RNNT_WD_STAMP(lb + 2, 0);
-            slot = slot + 1 == PSLOTS ? 0 : slot + 1;          // now the NEXT block's slot: its pairs landed an interval ago
-            const unsigned nsrc = pairs0 + (unsigned)slot * (unsigned)(K * WAVE * 8);
-            const unsigned nseed = seeds0 + (unsigned)((lb + 1) & (MIN_SLOTS - 1)) * (K * 4);
-            float* vslot = &sm.vals[lb & (VSLOTS - 1)][0][lane];
             // (no mailbox write on this wave: the storer rebuilds the boundary column from the values)
-            compute_block_ip<K, BETA, MODE, HAS_LEFT>(cur2, seed, nsrc, nseed, Y, X, d0, ucol_chk, Tn, vslot, d0 - wave_c);
+            compute_block_ip<K, BETA, MODE, HAS_LEFT>(cur2, seed4, nsrc, nseed, Y, X, d0, ucol_chk, Tn, vslot, d0 - wave_c);
             RNNT_WD_STAMP(lb + 2, 1);
+            ++lb;
+            prepare_block();
+            asm volatile("" : "+v"(nsrc), "+s"(nseed), "+v"(vslot));   // (worked out HERE, not behind the barrier)
             if (!dry) {
                 // the value stores and the in-place reloads of the block (inline assembly, which no fence of the compiler's
                 // counts) have to be complete: one explicit wait, with a "memory" clobber that also keeps the compiler's own
@@ -392,11 +407,11 @@ __device__ __forceinline__ void sweep(const LatticeArgs& a, const Item it, const
         };
         // head (lanes start), steady state, tail (lanes finish; for short lattices: everything): each variant exists once
 #pragma nounroll
-        for (; lb < head_end; ++lb) one_block(std::integral_constant<int, ws::BLOCK_HEAD>{});
+        while (lb < head_end) one_block(std::integral_constant<int, ws::BLOCK_HEAD>{});
 #pragma nounroll
-        for (; lb < full_end; ++lb) one_block(std::integral_constant<int, ws::BLOCK_FULL>{});
+        while (lb < full_end) one_block(std::integral_constant<int, ws::BLOCK_FULL>{});
 #pragma nounroll
-        for (; lb < tail_end; ++lb) one_block(std::integral_constant<int, ws::BLOCK_MASKED>{});
+        while (lb < tail_end) one_block(std::integral_constant<int, ws::BLOCK_MASKED>{});
         if (!dry) {
             for (int t = hi + 2; t < p1; ++t) block_barrier();
             if constexpr (!BETA) {
