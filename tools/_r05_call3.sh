@@ -1,7 +1,7 @@
 #!/bin/bash
 set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-OUT=$R/gpurun_out/r05c4
+OUT=$R/gpurun_out/r05c5
 mkdir -p $OUT
 cd $R
 export ROUTES_NO_PD=1

@@ -7,9 +7,14 @@ does not count.  The data lands some hundred cycles later; the only thing that m
 `s_waitcnt lgkmcnt(0)` in front of the block's barrier.  Nothing may read or write those registers in between -- and
 the one who could is the compiler (a register copy at a loop head, a spill, a reuse as a temporary), silently.
 
-This script compiles lattice_wd.hip for gfx950 with -save-temps (hipcc cross-compiles, no GPU needed), walks the
-generated ISA of every kernel in program order and reports any instruction that touches a register with a reload in
-flight.  Conservative along straight-line code and fall-through edges; an unconditional branch ends a path.
+Since round 5 the hand-written blocks even leave their last reloads in flight ACROSS the barrier (`s_waitcnt lgkmcnt(2)`
+instead of `(0)`) and retire them with a counted wait half-way through the next block.
+
+This script compiles lattice_wd.hip for gfx950 with -save-temps (hipcc cross-compiles, no GPU needed) and walks the
+generated ISA of every lattice kernel with the wave's LDS operations modelled as the in-order queue they are
+(`lgkmcnt(N)` retires all but the N youngest): any instruction that touches a register whose reload is still in the
+queue is reported.  One path per kernel: straight-line code, fall-through edges, unconditional branches followed once --
+which takes the walk around every loop body twice, the second time with what the first left in flight.
 
     python tools/check_inplace_reloads.py [file.s]        exit status 1 on a violation
 """
@@ -50,49 +55,88 @@ def compile_to_asm(src, extra=()):
 
 
 def check(path):
-    """Returns (kernels seen, in-place reloads seen, [violations])."""
-    kernels, reloads, bad = 0, 0, []
-    fn, in_asm, pending = None, False, {}
-    for ln, line in enumerate(open(path), 1):
-        s = line.split(";")[0].rstrip() if not line.lstrip().startswith(";;#") else line.strip()
-        if s.startswith(";;#ASMSTART"):
-            in_asm = True
-            continue
-        if s.startswith(";;#ASMEND"):
-            in_asm = False
-            continue
-        m = re.match(r"^(_Z\w+):", s)
+    """Returns (kernels seen, in-place reloads seen, [violations]).
+
+    Walks every lattice kernel along ONE path: straight-line code, the fall-through edge of conditional branches, and
+    unconditional branches followed to their label (each branch site once, which takes the walk around every loop body
+    a second time -- with whatever the first pass left in flight).  The wave's LDS operations are modelled as the
+    in-order queue they are: `s_waitcnt lgkmcnt(N)` retires all but the N youngest, and a register is "in flight" from
+    its reload until that reload retires."""
+    lines = open(path).read().split("\n")
+    # function extents and labels
+    funcs, cur = [], None
+    for i, line in enumerate(lines):
+        m = re.match(r"^(_Z\w+):", line)
         if m:
-            fn, pending = m.group(1), {}
-            kernels += "k_lattice" in fn
+            cur = [m.group(1), i, None, {}]
+            funcs.append(cur)
+        elif cur is not None and cur[2] is None:
+            lm = re.match(r"^(\.LBB\w+):", line)
+            if lm:
+                cur[3][lm.group(1)] = i
+            if re.match(r"^\s*s_endpgm", line):
+                cur[2] = i
+    kernels, reloads, bad = 0, 0, []
+    for fn, start, end, labels in funcs:
+        if "k_lattice" not in fn or end is None:
             continue
-        if fn is None or "k_lattice" not in fn or not s.strip() or s.lstrip().startswith("."):
-            continue
-        if re.match(r"^\s*s_endpgm", s):
-            fn = None
-            continue
-        if WAIT.match(s):
-            pending = {}
-            continue
-        if re.match(r"^\s*s_branch\b", s):
-            pending = {}
-            continue
-        r = RELOAD.match(s) if in_asm else None
-        touched = regs_of(s)
-        if r:
-            dst, addr = regs_of(r.group(2)), regs_of(r.group(3))
-            hit = addr & set(pending)
-            if hit:
-                bad.append((fn, ln, s.strip(), sorted(hit)))
-            reloads += 1
-            for v in dst:
-                pending[v] = ln
-            continue
-        hit = touched & set(pending)
-        if hit:
-            bad.append((fn, ln, s.strip(), sorted(hit)))
-            for v in hit:          # report a register once per reload
-                pending.pop(v, None)
+        kernels += 1
+        fifo = []            # [(line, regs-or-None)]: outstanding LDS operations, oldest first; regs for in-place reloads
+        followed, seen_reload_lines, reported = set(), set(), set()
+        i, in_asm, steps = start + 1, False, 0
+        while i <= end and steps < 400000:
+            steps += 1
+            raw = lines[i]
+            ln = i + 1
+            st = raw.strip()
+            if st.startswith(";;#ASMSTART"):
+                in_asm = True; i += 1; continue
+            if st.startswith(";;#ASMEND"):
+                in_asm = False; i += 1; continue
+            s = raw.split(";")[0].rstrip()
+            if not s.strip() or s.lstrip().startswith(".") or re.match(r"^\.?\w+:", s.strip()):
+                i += 1; continue
+            if re.match(r"^\s*s_endpgm", s):
+                break
+            w = re.match(r"^\s*s_waitcnt\b(.*)", s)
+            if w:
+                m = re.search(r"lgkmcnt\((\d+)\)", w.group(1))
+                if m:
+                    keep = int(m.group(1))
+                    fifo = fifo[len(fifo) - keep:] if keep else []
+                elif re.match(r"^\s*s_waitcnt\s+0\s*$", s):
+                    fifo = []
+                i += 1; continue
+            b = re.match(r"^\s*s_branch\s+(\.LBB\w+)", s)
+            if b:
+                if i in followed or b.group(1) not in labels:
+                    fifo = []      # this path has been walked: go on behind the branch as a fresh one
+                    i += 1
+                else:
+                    followed.add(i)
+                    i = labels[b.group(1)]
+                continue
+            pending = set()
+            for _, regs in fifo:
+                if regs:
+                    pending |= regs
+            r = RELOAD.match(s) if in_asm else None
+            touched = regs_of(s)
+            if r:
+                dst, addr = regs_of(r.group(2)), regs_of(r.group(3))
+                hit = addr & pending
+                if hit and ln not in reported:
+                    reported.add(ln); bad.append((fn, ln, s.strip(), sorted(hit)))
+                if ln not in seen_reload_lines:
+                    seen_reload_lines.add(ln); reloads += 1
+                fifo.append((ln, dst))
+                i += 1; continue
+            hit = touched & pending
+            if hit and ln not in reported:
+                reported.add(ln); bad.append((fn, ln, s.strip(), sorted(hit)))
+            if re.match(r"^\s*(ds_|s_load|s_buffer_load)", s):
+                fifo.append((ln, None))     # any other operation of the same counter: in the queue, nothing to protect
+            i += 1
     return kernels, reloads, bad
 
 

@@ -206,7 +206,7 @@ typedef __attribute__((address_space(3))) float lds_float;   // (a pointer that 
 template <int OFF0>
 __device__ __forceinline__ void lds_reload_2rows(f32x4& dst, const unsigned lds_byte_addr) {
     // rows OFF0 and OFF0 + 1 of a [KK][WAVE] block of pairs, this lane's column: two 8-byte reads 64 x 8 bytes apart
-    asm volatile("ds_read2st64_b64 %0, %1 offset0:%2 offset1:%3" : "=v"(dst) : "v"(lds_byte_addr), "n"(OFF0), "n"(OFF0 + 1));
+    asm volatile("ds_read2st64_b64 %0, %1 offset0:%2 offset1:%3" : "=v"(dst) : "v"(lds_byte_addr), "n"(OFF0), "n"(OFF0 + 1) : "memory");
 }
 template <int OFF>
 __device__ __forceinline__ void lds_reload_b32(float& dst, const unsigned lds_byte_addr) {
@@ -214,9 +214,18 @@ __device__ __forceinline__ void lds_reload_b32(float& dst, const unsigned lds_by
 }
 template <int OFF>
 __device__ __forceinline__ void lds_reload_b128(f32x4& dst, const unsigned lds_byte_addr) {
-    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(lds_byte_addr), "n"(OFF));
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(lds_byte_addr), "n"(OFF) : "memory");
 }
 __device__ __forceinline__ void wait_lds() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+// Wait until at most N of this wave's LDS operations are outstanding (they complete in order).  The hand-written blocks
+// end with the reloads of the registers the NEXT block uses last -- its last seeds, its last two pairs -- and leave them in
+// flight across the barrier (block_tail_in_flight), so that the wave does not sit out an LDS round trip at the end of
+// every block; half-way through the next block, with block_mid_wait reloads of its own issued since, one wait that by
+// then costs nothing makes sure they are in.  (Both counts are of inline-assembly reloads, which carry "memory" clobbers
+// so that the compiler's own LDS stores keep their place between them.)
+template <int N> __device__ __forceinline__ void wait_lds_but() { asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory"); }
+template <bool SEEDED> constexpr int block_tail_in_flight() { return SEEDED ? 2 : 1; }
+template <int KK, bool SEEDED> constexpr int block_mid_wait() { return KK / 4 + (SEEDED ? KK / 8 : 0); }
 
 #define RNNT_LSE_TAIL(T, E, MX, U)                                                                                      \
     "v_add_f32 " U ", 1.0, " E "\n\t"                                                                                    \
@@ -394,6 +403,7 @@ __device__ __forceinline__ void fast_steps(f32x4 (&cur2)[KK / 2], f32x4 (&seed4)
                                            float& Y, float& X, lds_float* vslot, const float log2e,
                                            const unsigned long long col0_mask, const unsigned long long rim0) {
     if constexpr (K_ < KK) {
+        if constexpr (K_ == KK / 2) wait_lds_but<block_mid_wait<KK, SEEDED>()>();   // the previous block's last reloads
         const float cx = (K_ & 1) ? cur2[K_ / 2].z : cur2[K_ / 2].x;
         const float cy = (K_ & 1) ? cur2[K_ / 2].w : cur2[K_ / 2].y;
         // (a head block starts before the column block's last column does: first_off + K_ <= 63 -- lattice_wd.hip; one
@@ -451,6 +461,7 @@ __device__ __forceinline__ void compute_block_ip(f32x4 (&cur2)[KK / 2], f32x4 (&
         return;
     }
 #define RNNT_PIN() __builtin_amdgcn_sched_barrier(0)
+    wait_lds();   // (a hand-written block in front of this one leaves its last reloads in flight)
     // (the order of the step is compute_block's: no hazard nops, see there)
     const int ucol_first = first_diag_of(ucol_chk);
     const bool col0 = ucol_chk == 0;

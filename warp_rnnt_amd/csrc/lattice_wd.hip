@@ -258,33 +258,11 @@ __device__ __forceinline__ void sweep(const LatticeArgs& a, const Item it, const
         for (int p = p0; p < p1; ++p) {
             RNNT_WD_STAMP(p, 2);
             wait_vmcnt<NDMA * (DLOAD - 1)>();                  // everything fetched DLOAD intervals ago has landed
-            if constexpr (RING_IN) {
-                const int m = p;
-                if (m >= lo && m < hi_left) {
-                    u64 g = sm.mail_raw[m & (MIN_SLOTS - 1)][mlane];
-                    if (!mail_valid(m, g)) {
-                        // fetched DLOAD intervals ago and the producer had not got there: this column block has
-                        // caught up with its neighbour.  Let the neighbour get LAG blocks ahead (or finish) before
-                        // going on, so that the look-ahead fetches of the following blocks find their data.
-#ifdef RNNT_WD_STATS
-                        const u64 t_wait = __builtin_amdgcn_s_memrealtime();
-#endif
-                        if (LAG > 0 && m > lo) mail_wait(min(m + LAG, hi_left - 1));   // (the first block: at once)
-                        g = mail_wait(m);
-                        // what was fetched ahead for the following blocks was fetched before this one existed: again
-                        // (older than anything the counted waits below wait for, so they only get more conservative)
-#pragma unroll
-                        for (int q = 1; q < DLOAD; ++q) {
-                            const int mq = min(m + q, hi_left - 1);
-                            if (lane < K / 2) dma16_agent(mq * (K * 8) + lane * 16, rs_ring, lds_raw + (unsigned)((m + q) & (MIN_SLOTS - 1)) * (K * 8));
-                        }
-#ifdef RNNT_WD_STATS
-                        if (lane == 0) trace[8 * (p + 8) + 4] = __builtin_amdgcn_s_memrealtime() - t_wait;
-#endif
-                    }
-                    if (lane < K) sm.mail_vals[m & (MIN_SLOTS - 1)][lane] = __builtin_bit_cast(float, (unsigned)g);
-                }
-            }
+            // The neighbour's granules of block p, as they landed: read now, looked at behind this interval's fetches (the
+            // LDS round trip in the shadow of their issue; the loader's interval must stay below the compute wave's).
+            const bool chk = RING_IN && p >= lo && p < hi_left;
+            u64 g = 0;
+            if constexpr (RING_IN) g = sm.mail_raw[p & (MIN_SLOTS - 1)][mlane];
             {
                 const int pl = p + DLOAD;
                 const bool live = pl >= lo && pl < hi;
@@ -313,6 +291,32 @@ __device__ __forceinline__ void sweep(const LatticeArgs& a, const Item it, const
                 const int mm = (ml >= lo && ml < hi_left) ? ml : lo;   // (always a block of the ring: the piece is
                                                                         //  issued regardless, its bytes not looked at)
                 if (lane < K / 2) dma16_agent(mm * (K * 8) + lane * 16, rs_ring, lds_raw + (unsigned)(ml & (MIN_SLOTS - 1)) * (K * 8));
+                if (chk) {
+                    const int m = p;
+                    if (!mail_valid(m, g)) {
+                        // fetched DLOAD intervals ago and the producer had not got there: this column block has
+                        // caught up with its neighbour.  Let the neighbour get LAG blocks ahead (or finish) before
+                        // going on, so that the look-ahead fetches of the following blocks find their data.
+#ifdef RNNT_WD_STATS
+                        const u64 t_wait = __builtin_amdgcn_s_memrealtime();
+#endif
+                        if (LAG > 0 && m > lo) mail_wait(min(m + LAG, hi_left - 1));   // (the first block: at once)
+                        g = mail_wait(m);
+                        // what was fetched ahead for the following blocks was fetched before this one existed: again --
+                        // and, these pieces being the youngest in the queue now, waited for here (the counted wait at the
+                        // head of the next interval would leave them in flight)
+#pragma unroll
+                        for (int q = 1; q < DLOAD; ++q) {
+                            const int mq = min(m + q, hi_left - 1);
+                            if (lane < K / 2) dma16_agent(mq * (K * 8) + lane * 16, rs_ring, lds_raw + (unsigned)((m + q) & (MIN_SLOTS - 1)) * (K * 8));
+                        }
+                        wait_vmcnt<0>();
+#ifdef RNNT_WD_STATS
+                        if (lane == 0) trace[8 * (p + 8) + 4] = __builtin_amdgcn_s_memrealtime() - t_wait;
+#endif
+                    }
+                    if (lane < K) sm.mail_vals[m & (MIN_SLOTS - 1)][lane] = __builtin_bit_cast(float, (unsigned)g);
+                }
             }
             RNNT_WD_STAMP(p, 3);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (its own LDS writes; NOT the pieces in flight)
@@ -400,7 +404,9 @@ __device__ __forceinline__ void sweep(const LatticeArgs& a, const Item it, const
                 // the value stores and the in-place reloads of the block (inline assembly, which no fence of the compiler's
                 // counts) have to be complete: one explicit wait, with a "memory" clobber that also keeps the compiler's own
                 // LDS accesses on their side of the barrier
-                ws::wait_lds();
+                // (the hand-written blocks leave the reloads the next block needs last in flight: lattice_step.h)
+                if constexpr (MODE == ws::BLOCK_MASKED) ws::wait_lds();
+                else ws::wait_lds_but<ws::block_tail_in_flight<HAS_LEFT>()>();
                 __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
             }
