@@ -71,6 +71,21 @@ def parse():
     return p.parse_args()
 
 
+def required_bytes(cfg, global_batch, rank, world):
+    """Device memory one rank's run of `cfg` needs at its peak, roughly: logits, log-probs (unless the log-softmax runs in
+    place), the loss entry's workspace and gathered gradients (16 + 8 bytes per lattice cell, rings aside), the copy
+    yardstick's scratch and the secondary timings' clones for the configurations that run them (not the in-place one)."""
+    N, T, U, V, _, _, inplace = cfg
+    if global_batch:
+        from warp_rnnt_amd.distributed import shard_bounds
+        lo, hi = shard_bounds(global_batch, rank, world)
+        N = max(hi - lo, 1)
+    dense = 4 * N * T * U * V
+    cells = N * T * U
+    peak = dense * (1 if inplace else 4) + 32 * cells + (64 << 20)
+    return peak
+
+
 def make_batch(cfg, rank, dev):
     N, T, U, V, *_ = cfg
     g = torch.Generator(device=dev)
@@ -316,6 +331,14 @@ def main():
         sys.exit(f"--gpus {a.gpus}: rank {rank} wants cuda:{local} but this node has {torch.cuda.device_count()} GPU(s)")
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
+    # Pre-flight, BEFORE anything is allocated: the device has room for this rank's share of the configuration (one clear
+    # line instead of an out-of-memory traceback from the middle of the batch generator, per rank, eight times over) ...
+    need = required_bytes(CONFIGS[a.config], a.global_batch, rank, world)
+    free, total = torch.cuda.mem_get_info(dev)
+    if need > free:
+        sys.exit(f"bench.py pre-flight: rank {rank} (cuda:{local}) needs about {need / 2**30:.1f} GiB for --config {a.config}"
+                 f"{' --global-batch ' + str(a.global_batch) if a.global_batch else ''} and has {free / 2**30:.1f} of "
+                 f"{total / 2**30:.1f} GiB free -- nothing was allocated")
     dist = None
     rccl_ranks = 1
     if world > 1 or "TORCHELASTIC_RUN_ID" in os.environ or a.rccl_group:
@@ -327,7 +350,18 @@ def main():
             with socket.socket() as s:
                 s.bind(("127.0.0.1", 0))
                 os.environ["MASTER_PORT"] = str(s.getsockname()[1])
-        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
+        try:
+            dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
+            # ... and the communicator works: one scalar through RCCL before the batch exists (a rank that cannot reach
+            # the others says so here, not after 144 GB of logits have been generated)
+            probe = torch.ones((1,), device=dev)
+            dist.all_reduce(probe)
+            torch.cuda.synchronize()
+            if int(probe.item()) != world:
+                raise RuntimeError(f"all-reduce over {world} rank(s) summed to {probe.item()}")
+            del probe
+        except Exception as e:      # noqa: BLE001  (whatever RCCL raises: report and stop, before any large allocation)
+            sys.exit(f"bench.py pre-flight: rank {rank} could not set up RCCL over {world} rank(s): {type(e).__name__}: {e}")
 
     from warp_rnnt_amd import _build
     _build.ensure_built()              # no-op when the prebuilt library travelled with the tree
@@ -462,6 +496,27 @@ def main():
         torch.cuda.synchronize()
         allreduce_us = (time.perf_counter() - t1) / a.steps * 1e6
 
+    # 4. the box's own yardstick, so that readings from different leases can be told apart from changes of the kernels:
+    #    a plain streaming copy of the log-softmax's bytes (the logits -> a scratch tensor of the same size; in place for
+    #    the config that runs its log-softmax in place), same stream, same conditioning (it runs right behind the timed
+    #    and pinned-route runs: the GPU is in its sustained-load state).  torch's vectorised elementwise kernel.
+    copy_gbs = None
+    try:
+        scratch = xs if inplace else torch.empty_like(xs)
+        for _ in range(3):
+            torch.mul(xs, 1.0, out=scratch)
+        c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        creps = max(5, min(a.steps, 20))
+        c0.record()
+        for _ in range(creps):
+            torch.mul(xs, 1.0, out=scratch)
+        c1.record()
+        torch.cuda.synchronize()
+        copy_gbs = 2.0 * xs.numel() * 4 / (c0.elapsed_time(c1) / creps * 1e-3) / 1e9
+        del scratch
+    except RuntimeError:      # (no room for the scratch tensor: the yardstick is left out, nothing else changes)
+        copy_gbs = None
+
     # dominant kernel (dense log-softmax stream): average launch duration from the HIP events
     # recorded inside the timed region, on the stream the kernel runs on
     k_ms = sum(ev_a[i].elapsed_time(ev_b[i]) for i in ev_steps) / len(ev_steps)
@@ -520,6 +575,11 @@ def main():
             # what a reference maintainer who links binding.cpp against this library gets
             from tools import cabi_probe
             extras.update(cabi_probe.time_entries(lp, ys, xn, yn, reps=max(3, min(reps, 10))))
+            # ... and its compact sequence (binding.cpp:139-204) on a ragged batch of this shape, next to the native
+            # compact entry on the same tensors
+            cx = cabi_probe.ragged_compact_batch(N, T, U, V, dev)
+            extras.update(cabi_probe.time_compact_entries(*cx, reps=max(3, min(reps, 10)), backward=False))
+            del cx
         if gather:
             extras["roofline_gather"] = gather_roofline(lp, ys, N, T, U, V, reps)
         del lp
@@ -588,7 +648,10 @@ def main():
             "loss_checksum": round(loss_val, 3),
             "roofline": {"bound": "hbm", "kernel": "k_lsm_regs / k_lsm_small / k_lsm_large (log-softmax over V)",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4),
+                         # the same against what a plain copy of those bytes reaches on THIS box in THIS run (copy_gbs)
+                         "frac_of_copy": None if not copy_gbs else round(achieved / copy_gbs, 4),
+                         "traffic": traffic,
                          "traffic_source": traffic_src,
                          "algorithmic_bytes": alg_bytes, "kernel_ms": round(k_ms, 4)},
             # north_star asks for ">= 60 % of HBM peak on the gather path": this is that path, priced the same way
@@ -599,6 +662,7 @@ def main():
                                    "achieved": round(g_achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                    "frac": round(g_achieved / HBM_PEAK_GBS, 4), "traffic": None,
                                    "algorithmic_bytes": g_bytes, "kernels_ms": round(g_ms, 4)},
+            "copy_gbs": None if not copy_gbs else round(copy_gbs, 1),   # plain streaming copy of the same bytes, this box
             "rccl_ranks": rccl_ranks,
             "rccl_group": dist is not None,     # True: every step ended in costs.sum() + one RCCL all-reduce
             "preload_ms": a.preload_ms,         # streaming copies enqueued in front of the warm-up steps (not steps)

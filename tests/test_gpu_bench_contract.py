@@ -70,5 +70,12 @@ def test_c4_line_prices_the_loss_entry_and_the_gather_too():
     assert d["lattice_route"] == "auto -> lattice_wd"
     assert d["max_abs_grad_vs_oracle"] <= 3e-3 and d["max_abs_grad_vs_oracle_p999"] <= 5e-5
     assert d["step_torch_log_softmax_ms"] > d["ms_per_step"]       # torch's log-softmax is the slower one
+    # the box's own yardstick travels with the line: a plain copy of the log-softmax's bytes in this run, and the dominant
+    # kernel's rate against it (readings from different leases differ by +-4 %, the ratio does not)
+    assert 3000.0 < d["copy_gbs"] < 8000.0
+    assert abs(d["roofline"]["frac_of_copy"] - d["roofline"]["achieved"] / d["copy_gbs"]) < 2e-3
+    assert 0.6 < d["roofline"]["frac_of_copy"] < 1.25
+    # the reference binding's compact sequence on the reference-named entry points, next to the native compact entry
+    assert 0.0 < d["native_compact_ms"] < d["cabi_compact_ms"] < 3.0 * d["native_compact_ms"]
     # the two halves of the step, as the events saw them, make up the step (launch gaps and event packets aside)
     assert abs(d["roofline"]["kernel_ms"] + lp["kernels_ms"] - d["ms_per_step"]) < 0.15 * d["ms_per_step"]

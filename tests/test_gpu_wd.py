@@ -48,7 +48,10 @@ SHAPES = [(3, 37, 70, True), (2, 5, 130, False), (4, 200, 65, True), (2, 150, 64
           (5, 333, 129, True), (4, 600, 300, True), (2, 64, 512, False), (70, 90, 200, True), (3, 1, 100, True),
           (2, 700, 257, False), (300, 40, 130, True),
           # one column block per sweep: the plain launch (no rings, no queue, no redo kernel behind)
-          (300, 40, 33, True), (3, 5, 20, True), (2, 1, 30, False), (130, 200, 64, True), (3, 100, 1, False)]
+          (300, 40, 33, True), (3, 5, 20, True), (2, 1, 30, False), (130, 200, 64, True), (3, 100, 1, False),
+          # from 1024 frames of launch bound on the column-block kernel works in blocks of 16 diagonals (its second
+          # instantiation, csrc/lattice_wd_body.h): lone, two and five column blocks, ragged and not, U - 1 on a block edge
+          (3, 1030, 40, True), (2, 1100, 70, True), (2, 1200, 300, False), (3, 1024, 129, True), (2, 1500, 17, False)]
 
 
 @pytest.mark.parametrize("N,T,U,ragged", SHAPES)

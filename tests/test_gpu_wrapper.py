@@ -336,3 +336,13 @@ def test_benchmark_table_cli(loss, tmp_path):
     assert len(table) == 2 + 4 and table[0].startswith("| T | U | V | N |")
     # the reference's published cell is quoted where there is one (README.md:38: T=150,U=40,V=28,N=1)
     assert table[4].split("|")[6].strip() in ("0.5", "0.54")
+
+
+def test_python_dash_m_warp_rnnt_test():
+    """The package's self-test entry point (the reference: pytorch_binding/README.md:76-79) runs green on the GPU."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-m", "warp_rnnt.test"], cwd=root, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    assert "OK" in out.stderr and "skipped" not in out.stderr

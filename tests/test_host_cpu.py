@@ -433,3 +433,17 @@ def test_in_place_reloads_of_the_lattice_kernels_are_not_touched_before_their_wa
     with open(bpath, "w") as f:
         f.write(broken)
     assert len(chk.check(bpath)[2]) == 1
+
+
+def test_package_self_test_ships_the_golden_data_and_skips_cleanly_without_a_gpu():
+    """`python -m warp_rnnt.test` (pytorch_binding/README.md:76-79): the data file inside the package is the repository's
+    golden file, byte for byte; on a machine without a GPU every case is skipped (there is no CPU path to fall back to)
+    and the command exits 0."""
+    with open(os.path.join(ROOT, "warp_rnnt", "golden_vectors.json"), "rb") as f, \
+            open(os.path.join(GOLDEN, "reference_vectors.json"), "rb") as g:
+        assert f.read() == g.read()
+    if torch.cuda.is_available():
+        pytest.skip("the GPU suite runs it for real (tests/test_gpu_wrapper.py)")
+    out = subprocess.run([sys.executable, "-m", "warp_rnnt.test"], cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "skipped" in out.stderr and "FAILED" not in out.stderr

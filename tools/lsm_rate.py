@@ -48,7 +48,26 @@ for V, gb, variant, chunk in cases:
         torch.cuda.synchronize()
         ts.append(e0.elapsed_time(e1) / 10)
     ms = statistics.median(ts)
+    copy_txt = ""
+    if os.environ.get("LSM_COPY"):
+        # the yardstick: a plain streaming copy of the same bytes on the same stream, same conditioning -- torch's
+        # vectorised elementwise kernel, out of place (dst = src * 1) or, for the in-place runs, x *= 1 (reads and writes
+        # the same addresses, as the in-place log-softmax does)
+        cp = (lambda: torch.mul(x, 1.0, out=x)) if inplace else (lambda: torch.mul(x, 1.0, out=out))
+        for _ in range(20):
+            cp()
+        tc = []
+        for _ in range(5):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(10):
+                cp()
+            e1.record()
+            torch.cuda.synchronize()
+            tc.append(e0.elapsed_time(e1) / 10)
+        cms = statistics.median(tc)
+        copy_txt = f"   copy {2 * rows * V * 4 / cms / 1e9:6.2f} TB/s  (log-softmax / copy {cms / ms:5.3f})"
     streams = 3 if backward else 2
     print(f"V={V:6d} rows={rows:9d} in={rows * V * 4 / 1e9:5.2f} GB  {ms * 1e3:8.1f} us  {streams * rows * V * 4 / ms / 1e9:6.2f} TB/s"
-          f"{' (backward: dy, y in, dx out)' if backward else ''}{' (in place)' if inplace else ''}", flush=True)
+          f"{' (backward: dy, y in, dx out)' if backward else ''}{' (in place)' if inplace else ''}{copy_txt}", flush=True)
     del x, out

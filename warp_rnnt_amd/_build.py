@@ -13,7 +13,8 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libwarp_rnnt_amd.so")
 SOURCES = ["api.hip", "lattice.hip", "lattice_ws.hip", "lattice_wd.hip", "lattice_pd.hip", "grads.hip", "prologue.hip",
            "expand.hip"]
-HEADERS = ["common.h", "kernels.h", "lattice_step.h", "grads_cell.h", os.path.join("..", "..", "include", "warp_rnnt_amd.h")]
+HEADERS = ["common.h", "kernels.h", "lattice_step.h", "lattice_wd_body.h", "grads_cell.h",
+           os.path.join("..", "..", "include", "warp_rnnt_amd.h")]
 ARCH = "gfx950"
 
 
@@ -58,8 +59,6 @@ VARIANTS = {
     # hand-over waits that give up at once: every column block that catches up with its neighbour flags its sweep
     # for the log-domain kernel (the "producer lost" path, which never triggers otherwise)
     "short_spin": ["-DRNNT_PD_SPIN_LIMIT=0", "-DRNNT_WD_SPIN_LIMIT=0"],
-    # A/B (tools/lattice_routes.py): blocks of 16 diagonals per barrier in the column-block kernel instead of 8
-    "wd_k16": ["-DRNNT_WD_K=16", "-DRNNT_WL_DEFAULT_MAX_BLOCKS=0"],
     # A/B of k_lattice_wl's wave placement: six waves in column-block-major order / compute waves at raised priority
     "wl_nopad": ["-DRNNT_WL_PAD=0"],
     "wl_prio": ["-DRNNT_WL_PRIO=2"],
