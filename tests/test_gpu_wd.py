@@ -77,7 +77,8 @@ def test_same_bits_as_the_single_workgroup_kernel(N, T, U, ragged):
         o = oracle.rnnt_loss_f32(lp2.cpu().numpy(), None, xn, yn, blank=-1, fastemit_lambda=0.01)
         # (two fp32 implementations of one operation order: 1e-4 up to T+U ~ 200, the rounding of |alpha| beyond)
         np.testing.assert_allclose(c_wd.cpu().numpy(), o["costs"], rtol=1e-5)
-        np.testing.assert_allclose(g_wd.cpu().numpy(), o["grads"], atol=1e-4 if T + U <= 250 else 3e-4)
+        # (... 3e-3 from a thousand frames on: one rounding of |alpha| ~ 4e3 on best-path cells, tests/test_gpu_baseline_sizes.py)
+        np.testing.assert_allclose(g_wd.cpu().numpy(), o["grads"], atol=1e-4 if T + U <= 250 else 3e-4 if T + U <= 900 else 3e-3)
 
 
 def test_default_route_picks_either_kernel_by_batch_and_the_bits_do_not_change():

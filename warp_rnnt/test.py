@@ -111,8 +111,8 @@ class KnownAnswers(unittest.TestCase):
             np.testing.assert_allclose(x.grad.cpu().numpy(), want_g, atol=TOL, rtol=0)
         x = lp.clone().requires_grad_(True)
         mean = warp_rnnt.rnnt_loss(x, ys, xn, yn, reduction="mean", average_frames=True)
-        self.assertAlmostEqual(float(mean), float(np.mean(want_c / np.array(case["xn"]))), places=5)
-        with self.assertRaises(ValueError):
+        self.assertAlmostEqual(mean.item(), float(np.mean(want_c / np.array(case["xn"]))), places=5)
+        with self.assertRaises((AssertionError, ValueError)):      # (the reference asserts on the flag before it gets there)
             warp_rnnt.rnnt_loss(lp, ys, xn, yn, reduction="median")
 
 

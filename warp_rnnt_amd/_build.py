@@ -61,8 +61,7 @@ VARIANTS = {
     "short_spin": ["-DRNNT_PD_SPIN_LIMIT=0", "-DRNNT_WD_SPIN_LIMIT=0"],
     # A/B of k_lattice_wl's wave placement: six waves in column-block-major order / compute waves at raised priority
     "wl_nopad": ["-DRNNT_WL_PAD=0"],
-    "wl_prio": ["-DRNNT_WL_PRIO=2"],
-    "wl_nopad_prio": ["-DRNNT_WL_PAD=0", "-DRNNT_WL_PRIO=2"],
+    "wl_noprio": ["-DRNNT_WL_PRIO=0"],
 }
 
 

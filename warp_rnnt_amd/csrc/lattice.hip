@@ -584,7 +584,12 @@ hipError_t launch_lattice(hipStream_t stream, const LatticeArgs& a, int N, int l
         // queue up behind each other when five workgroups share a CU) and the sweep is long enough to recover two
         // extra launches (ring preparation in front, the idle redo kernel behind).
         const int kern = logdomain_kernel();
-        bool use_wd = ring_ok && (long long)2 * N * nA <= 2ll * device_cus(stream) && a.T >= 640 && (nA >= 2 || a.T >= 1024);
+        // (round 5, after the hand-written blocks, ws / wd / wl: two column blocks -- the single-workgroup form wl at every
+        //  size: N=16, T=1500, U=128 116 / 83 / 82, T=700, U=100 61 / 48 / 45, T=400 42 / 35 / 31, N=32, T=250 32 / 30 / 25,
+        //  N=64, T=300, U=128 39 / 36 / 30; three and more: wd while the chip has CUs for its workgroups and the sweep
+        //  is long: N=16, T=1500, U=300 161 / 102 / 128, N=32, T=1000, U=200 100 / 72 / 75; N=32, T=500, U=200 64 / 52 / 51;
+        //  full chips: N=64, T=1500, U=300 199 / 192 / 189, N=128 307 / 414 / 335 -- profiles/r05_lattice_routes.txt)
+        bool use_wd = ring_ok && (long long)2 * N * nA <= 2ll * device_cus(stream) && a.T >= 640 && nA >= 3;
         if (nA > ws::MAXA_HOST) use_wd = ring_ok;             // wider than one workgroup sweeps: column blocks or stripes
         if (kern == 1) use_wd = false;
         if (kern == 2) use_wd = ring_ok;
@@ -612,7 +617,10 @@ hipError_t launch_lattice(hipStream_t stream, const LatticeArgs& a, int N, int l
         // profiles/r05_lattice_routes.txt).  Needs nothing but the planes, so it also serves the callers without flags
         // and rings (the reference-named C entry points, 32-bit compact offsets).
         if (kern != 1 && nA >= 2) {
-            const hipError_t e = launch_lattice_wl(stream, plain, N, kern == 3 ? 5 : wl_max_blocks());
+            // (by itself: two column blocks always, up to five while one workgroup per sweep leaves CUs idle -- beyond
+            //  ~100 utterances lattice_ws.hip's ten waves per workgroup pack the chip better than fifteen)
+            const int by_shape = (nA <= 2 || N <= 96) ? wl_max_blocks() : 2;
+            const hipError_t e = launch_lattice_wl(stream, plain, N, kern == 3 ? 5 : by_shape);
             if (e != hipErrorNotSupported) { g_last_kernel = 5; return e; }
         }
         const hipError_t e = launch_lattice_ws(stream, plain, N);

@@ -128,8 +128,9 @@ hipError_t launch_lattice_wd(hipStream_t stream, const LatticeArgs& a0, int N) {
 // Padded or compact (either offset width); honours a.redo (only the flagged sweeps) and a.beta_only.
 // hipErrorNotSupported when the lattice is wider than the workgroup's LDS holds (wl_max_blocks() column blocks).
 int wl_max_blocks() {
-    // 2 column blocks (U <= 128) fit the 64 KiB every kernel gets; 5 (U <= 320) need the large-LDS opt-in, 148 KiB of
-    // the CU's 160.  RNNT_WL_MAX_BLOCKS = 0 ... 5 overrides (0: the kernel is never chosen), for A/B runs.
+    // 2 column blocks (U <= 128) fit the 64 KiB every kernel gets; 5 (U <= 320) take the large-LDS opt-in, 148 KiB of
+    // the CU's 160 (LDS-DMA lands above 64 KiB as well: M0 carries the full address on gfx950 -- tests/test_gpu_wd.py).
+    // RNNT_WL_MAX_BLOCKS = 0 ... 5 overrides (0: the kernel is never chosen), for A/B runs.
     static const int v = [] {
         const char* e = getenv("RNNT_WL_MAX_BLOCKS");
         const int d = e ? atoi(e) : RNNT_WL_DEFAULT_MAX_BLOCKS;

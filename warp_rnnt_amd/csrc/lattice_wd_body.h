@@ -37,10 +37,10 @@ constexpr int SPIN_LIMIT = RNNT_WD_SPIN_LIMIT;   // polls before a hand-over is 
 #define RNNT_WL_PAD 1          // two column blocks: eight waves, the compute waves alone on their SIMDs (k_lattice_wl)
 #endif
 #ifndef RNNT_WL_PRIO
-#define RNNT_WL_PRIO 0         // s_setprio of the compute waves of k_lattice_wl (0: none)
-#endif
+#define RNNT_WL_PRIO 2         // s_setprio of the compute waves of k_lattice_wl from three column blocks on, where they
+#endif                         // share SIMDs with loaders and storers (N=16, T=1500, U=300: 142 -> 137 us; nothing at two)
 #ifndef RNNT_WL_DEFAULT_MAX_BLOCKS
-#define RNNT_WL_DEFAULT_MAX_BLOCKS 2
+#define RNNT_WL_DEFAULT_MAX_BLOCKS 5
 #endif
 constexpr int LAG = RNNT_WD_LAG; // blocks a column block lets its left neighbour get ahead once it has caught up with it
 
@@ -537,7 +537,7 @@ __global__ void __launch_bounds__((NA_MAX == 2 ? 8 : 3 * NA_MAX) * WAVE) k_latti
         idx = w / 3; role = w - 3 * idx;
         nA = blockDim.x / (3 * WAVE);
     }
-    if (RNNT_WL_PRIO && role == 0) __builtin_amdgcn_s_setprio(RNNT_WL_PRIO);   // (A/B: the dependent chain first)
+    if (RNNT_WL_PRIO && role == 0 && nA >= 3) __builtin_amdgcn_s_setprio(RNNT_WL_PRIO);   // (the dependent chain first)
     Item it;
     it.n = (int)n; it.dir = (int)dir; it.cb = idx;
     if (len.Un == 1) {                                 // no labels: one wave's prefix / suffix sums (uniform, no barrier)
