@@ -52,8 +52,27 @@ __global__ void __launch_bounds__(256) k_lds(const f4* __restrict__ a, f4* __res
     for (int i = lane; i < 200; i += 64) if (base + i < n) b[base + i] = tile[w][i];
 }
 
+// READ-ONLY streams: what a kernel that reads the tensor and writes (next to) nothing can reach -- the yardstick of the
+// fused logits -> pairs kernel (4V + 8 bytes per cell, of which 8 written).  UN float4 per thread, loads first; one lane per
+// wave keeps the compiler honest with a 4-byte store of a sum.
+template <int UN, bool NT>
+__global__ void __launch_bounds__(256) k_read(const f4* __restrict__ a, float* __restrict__ sink, size_t n) {
+    const size_t base = (size_t)blockIdx.x * 256 * UN + threadIdx.x;
+    f4 v[UN];
+#pragma unroll
+    for (int j = 0; j < UN; ++j) {
+        const size_t i = base + (size_t)j * 256;
+        v[j] = f4{0.f, 0.f, 0.f, 0.f};
+        if (i < n) v[j] = NT ? __builtin_nontemporal_load(a + i) : a[i];
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < UN; ++j) s += v[j].x + v[j].y + v[j].z + v[j].w;
+    if (s == 123456.789f) sink[blockIdx.x] = s;          // (never true for this data: the loads cannot be dropped)
+}
+
 template <typename F>
-static void run(const char* name, F launch, size_t bytes) {
+static void run(const char* name, F launch, size_t bytes, double streams = 2.0) {
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
     std::vector<float> ts;
@@ -67,7 +86,7 @@ static void run(const char* name, F launch, size_t bytes) {
     }
     std::sort(ts.begin(), ts.end());
     printf("%-44s median %7.1f us  min %7.1f us   %.2f TB/s (median)\n", name, ts[ts.size() / 2] * 1e3, ts[0] * 1e3,
-           2.0 * bytes / (ts[ts.size() / 2] * 1e-3) / 1e12);
+           streams * bytes / (ts[ts.size() / 2] * 1e-3) / 1e12);
 }
 
 int main(int argc, char** argv) {
@@ -87,5 +106,14 @@ int main(int argc, char** argv) {
     run("grid-stride 2048 blocks x 4", [&] { k_stride<4><<<2048, 256>>>(a, b, n); }, bytes);
     run("grid-stride 4096 blocks x 2", [&] { k_stride<2><<<4096, 256>>>(a, b, n); }, bytes);
     run("LDS-staged, 3.2 KB per wave", [&] { k_lds<<<(unsigned)((n + 799) / 800), 256>>>(a, b, n); }, bytes);
+    printf("read-only stream of %.2f GB (TB/s of bytes READ)\n", bytes / 1e9);
+    float* sink = reinterpret_cast<float*>(b);
+    run("read only, 1 float4 / thread", [&] { k_read<1, false><<<(unsigned)((n + 255) / 256), 256>>>(a, sink, n); }, bytes, 1.0);
+    run("read only, 2 float4 / thread", [&] { k_read<2, false><<<(unsigned)((n + 511) / 512), 256>>>(a, sink, n); }, bytes, 1.0);
+    run("read only, 4 float4 / thread", [&] { k_read<4, false><<<(unsigned)((n + 1023) / 1024), 256>>>(a, sink, n); }, bytes, 1.0);
+    run("read only, 1 float4 / thread, nontemporal", [&] { k_read<1, true><<<(unsigned)((n + 255) / 256), 256>>>(a, sink, n); }, bytes, 1.0);
+    run("read only, 2 float4 / thread, nontemporal", [&] { k_read<2, true><<<(unsigned)((n + 511) / 512), 256>>>(a, sink, n); }, bytes, 1.0);
+    run("read only, 4 float4 / thread, nontemporal", [&] { k_read<4, true><<<(unsigned)((n + 1023) / 1024), 256>>>(a, sink, n); }, bytes, 1.0);
+    run("read only, 8 float4 / thread, nontemporal", [&] { k_read<8, true><<<(unsigned)((n + 2047) / 2048), 256>>>(a, sink, n); }, bytes, 1.0);
     return 0;
 }

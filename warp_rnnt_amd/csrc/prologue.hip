@@ -162,15 +162,50 @@ k_lsm_small(const float* x, float* out, const int* __restrict__ labels,
 
     // ---- stage: the tile is a plain copy of the chunk ----
     const int nvec = nel >> 2;
+    // fused backward: the gradient pair (and scale) of the row this thread works on first, requested before the tile
+    [[maybe_unused]] CellMap pm = {0, 0, 0};
+    [[maybe_unused]] float2 pg = make_float2(0.0f, 0.0f);
+    [[maybe_unused]] float psc = 1.0f;
+    if constexpr (MODE == LSM_BWD) {
+        pm = map_cell((size_t)(row0 + min(tid / L, nrows - 1)), labels, T, U, V, blank);
+        pg = bw.g2[pm.sk];
+        psc = bw.scale ? bw.scale[pm.n] : 1.0f;
+    }
+    // LOADS FIRST (round 5).  Written as `for (i ...) tile[i] = load(src + i)` the compiler emits load, s_waitcnt vmcnt(0),
+    // ds_write per iteration: a wave had ONE 16-byte load per lane in flight at a time and paid the memory latency three
+    // to four times per tile -- 1 KB per wave in flight, 32 KB per CU, which at ~1.5 us of loaded latency is the 5.2 TB/s
+    // the fused gather ran at (read-only streams reach 7.0, tools/ubench/copy_rate.hip).  A tile is at most four passes
+    // of the threads that stage it (SM_FLOATS, and V <= 16 L for the wave-private form): all of a lane's loads are
+    // issued before the first of them is written to LDS -- unconditionally, at an index clamped into the tile, and so are
+    // the LDS writes (lanes past the end rewrite the tile's last 16 bytes with the bytes that are there).  A predicate per
+    // load comes out as a branch per load with a conservative wait at every join; predicates on the writes alone and the
+    // compiler sinks the loads into them.
+    constexpr int STAGE_UN = WP ? 4 : (SM_FLOATS / 4 + SM_THREADS - 1) / SM_THREADS;   // (3200 floats, 256 threads: 4)
     if constexpr (WP) {
+        const float4* wsrc4 = reinterpret_cast<const float4*>(src + (size_t)wr0 * V);
+        for (int base = lane; base < wvec; base += STAGE_UN * WAVE) {
+            float4 sv[STAGE_UN];
+#pragma unroll
+            for (int k = 0; k < STAGE_UN; ++k)
+                sv[k] = RNNT_LSM_LOAD(wsrc4 + min(base + k * WAVE, wvec - 1));
+#pragma unroll
+            for (int k = 0; k < STAGE_UN; ++k)
+                reinterpret_cast<float4*>(wtile)[min(base + k * WAVE, wvec - 1)] = sv[k];
+        }
         const float* wsrc = src + (size_t)wr0 * V;
-        for (int i = lane; i < wvec; i += WAVE)
-            reinterpret_cast<float4*>(wtile)[i] = RNNT_LSM_LOAD(reinterpret_cast<const float4*>(wsrc) + i);
         for (int e = (wvec << 2) + lane; e < wel; e += WAVE) wtile[e] = wsrc[e];
         wave_sync_lds();
     } else {
-        for (int i = tid; i < nvec; i += SM_THREADS)
-            reinterpret_cast<float4*>(tile)[i] = RNNT_LSM_LOAD(reinterpret_cast<const float4*>(src) + i);
+        const float4* src4 = reinterpret_cast<const float4*>(src);
+        for (int base = tid; base < nvec; base += STAGE_UN * SM_THREADS) {
+            float4 sv[STAGE_UN];
+#pragma unroll
+            for (int k = 0; k < STAGE_UN; ++k)
+                sv[k] = RNNT_LSM_LOAD(src4 + min(base + k * SM_THREADS, nvec - 1));
+#pragma unroll
+            for (int k = 0; k < STAGE_UN; ++k)
+                reinterpret_cast<float4*>(tile)[min(base + k * SM_THREADS, nvec - 1)] = sv[k];
+        }
         for (int e = (nvec << 2) + tid; e < nel; e += SM_THREADS) tile[e] = src[e];   // last chunk only
         __syncthreads();
     }
@@ -205,9 +240,10 @@ k_lsm_small(const float* x, float* out, const int* __restrict__ labels,
         if constexpr (GATHER) {
             if (h == 0) stat[r] = make_float2(mx, ls);
         } else if constexpr (MODE == LSM_BWD) {
-            const CellMap m = map_cell((size_t)(row0 + r), labels, T, U, V, blank);
-            const float sc = bw.scale ? bw.scale[m.n] : 1.0f;
-            const float2 g = bw.g2[m.sk];
+            const bool first = r == rr;                // (the row whose pair was requested up front)
+            const CellMap m = first ? pm : map_cell((size_t)(row0 + r), labels, T, U, V, blank);
+            const float sc = first ? psc : (bw.scale ? bw.scale[m.n] : 1.0f);
+            const float2 g = first ? pg : bw.g2[m.sk];
             const float gB = g.x * sc, gL = g.y * sc, gs = gB + gL;
             const float mb2 = -(mx + ls) * LOG2E;
 #pragma unroll
@@ -354,14 +390,60 @@ k_lsm_large(const float* x, float* out, const int* __restrict__ labels,
     if (row >= (size_t)rows) continue;
     const float4* src = reinterpret_cast<const float4*>(x + row * V);
     const int nvec = V >> 2;
+    // How a lane's LG_MAXVEC loads are issued (round 5).  As first written -- load and running maximum together under
+    // `if (j < nvec)` -- every load sits in a branch of its own with an s_waitcnt vmcnt(0) behind it: LG_MAXVEC memory
+    // round trips per row, one after the other.  Measured against two loads-first forms (tools/ab_kernels.py, three
+    // interleaved rounds, profiles/r05_loads_first_ab.txt):
+    //   * the read-mostly FUSED modes gain 5-7 % from all loads issued unconditionally at an index clamped into the row,
+    //     what lies beyond the row replaced by -inf afterwards (c3: fused forward 317 -> 300 us, fused backward 739 -> 689);
+    //   * the plain log-softmax -- a read and a write stream at the rate of a copy -- does not: V = 5000 629 -> 647 us,
+    //     4096 596 -> 606, 2048 590 -> 594, nothing at 1000, 3000, 8192; only the three-pass covers of 768 threads and more
+    //     gain (c5's V = 10000: 693 -> 674 clamped, -> 665 with the loads alone under their predicates and the maxima
+    //     behind them), so those take the predicated form and everything else stays as it was.
+    constexpr bool CLAMPED = MODE != LSM_NORM;
+    constexpr bool PREDICATED = MODE == LSM_NORM && LG_THREADS >= 768;
+    constexpr bool NT_LOADS = (((MODE == LSM_NORM ? 1 : RNNT_LG_NT_FUSED) * RNNT_LG_NT) & 1) != 0;
     float4 v[LG_MAXVEC];
     float mx = -__builtin_inff();
+    if constexpr (CLAMPED || PREDICATED) {
+#pragma unroll
+        for (int i = 0; i < LG_MAXVEC; ++i) {
+            const int j = (int)threadIdx.x + i * LG_THREADS;
+            if constexpr (CLAMPED) {
+                v[i] = NT_LOADS ? rnnt_nt_load4(src + min(j, nvec - 1)) : src[min(j, nvec - 1)];
+            } else {
+                if (j < nvec) v[i] = NT_LOADS ? rnnt_nt_load4(src + j) : src[j];
+            }
+        }
+    }
+    // what the fused modes need besides the row, requested behind it instead of after the reductions
+    [[maybe_unused]] CellMap m = {0, 0, 0};
+    [[maybe_unused]] float2 side = make_float2(0.0f, 0.0f);      // GATHER: the row's (blank, label) logits; BWD: its gradient pair
+    [[maybe_unused]] float sc = 1.0f;
+    if constexpr (MODE != LSM_NORM) {
+        m = map_cell(row, labels, T, U, V, blank);
+        if constexpr (GATHER) {
+            const float* xr = x + row * V;
+            side = make_float2(xr[blank], xr[m.label]);
+        } else {
+            side = bw.g2[m.sk];
+            sc = bw.scale ? bw.scale[m.n] : 1.0f;
+        }
+    }
 #pragma unroll
     for (int i = 0; i < LG_MAXVEC; ++i) {
-        const int j = threadIdx.x + i * LG_THREADS;
-        if (j < nvec) {
-            v[i] = (((MODE == LSM_NORM ? 1 : RNNT_LG_NT_FUSED) * RNNT_LG_NT) & 1) ? rnnt_nt_load4(src + j) : src[j];
+        const int j = (int)threadIdx.x + i * LG_THREADS;
+        if constexpr (CLAMPED || PREDICATED) {
+            if (j >= nvec) {
+                const float ninf = -__builtin_inff();
+                v[i] = make_float4(ninf, ninf, ninf, ninf);
+            }
             mx = fmaxf(fmaxf(mx, fmaxf(v[i].x, v[i].y)), fmaxf(v[i].z, v[i].w));
+        } else {
+            if (j < nvec) {
+                v[i] = NT_LOADS ? rnnt_nt_load4(src + j) : src[j];
+                mx = fmaxf(fmaxf(mx, fmaxf(v[i].x, v[i].y)), fmaxf(v[i].z, v[i].w));
+            }
         }
     }
     mx = block_reduce<LG_THREADS>(mx, true, red);
@@ -377,16 +459,10 @@ k_lsm_large(const float* x, float* out, const int* __restrict__ labels,
     s = block_reduce<LG_THREADS>(s, false, red);
     const float ls = logf(s);
     if constexpr (GATHER) {
-        if (threadIdx.x == 0) {
-            const CellMap m = map_cell(row, labels, T, U, V, blank);
-            const float* xr = x + row * V;
-            reinterpret_cast<float2*>(out)[m.sk] =
-                make_float2((xr[blank] - mx) - ls, (xr[m.label] - mx) - ls);
-        }
+        if (threadIdx.x == 0)
+            reinterpret_cast<float2*>(out)[m.sk] = make_float2((side.x - mx) - ls, (side.y - mx) - ls);
     } else if constexpr (MODE == LSM_BWD) {
-        const CellMap m = map_cell(row, labels, T, U, V, blank);
-        const float sc = bw.scale ? bw.scale[m.n] : 1.0f;
-        const float2 g = bw.g2[m.sk];
+        const float2 g = side;
         const float gB = g.x * sc, gL = g.y * sc, gs = gB + gL;
         const float mb2 = -(mx + ls) * LOG2E;
         float4* dst = reinterpret_cast<float4*>(out + row * V);
@@ -818,6 +894,13 @@ static hipError_t dispatch_lsm(hipStream_t stream, const float* x, float* out, c
         }
     }
     if constexpr (MODE == LSM_GATHER) {
+        // V % 4 != 0 (c4's own V = 50: rows that pack into 16-byte groups only in twos) stays on the LDS-staged kernel below.
+        // Round 5 tried the rows-in-registers loads of k_lsm_regs for it once more, with what round 4 had learnt on
+        // k_lsm_rows -- the lane that stores a row's pair asks for its two logits itself, ahead of the group loads, or picks
+        // them out of an LDS copy of the groups: whole fused forward at c4 503-512 us (two and four groups per half-wave:
+        // 558 / 503; LDS copy 512) against 419-433 for the LDS-staged kernel then, and ~400 since its staging loop issues
+        // its loads first (k_lsm_small; the kernel alone 290 -> 225-255 us, 5.6-6.4 TB/s read against 7.0 for a bare
+        // read-only stream, tools/ubench/copy_rate.hip, profiles/r05_loads_first_ab.txt).
         // Rows in registers, L lanes per row (k_lsm_rows), against the LDS-staged kernel below -- re-measured after that
         // kernel got its straight-line row pass (forward of the fused entry, N=32, T=500, U=100, us, k_lsm_rows / LDS tiles;
         // tools/fused_rate.py, profiles/r04_lsm_rows_ab.txt section 9): V=32 97 / 127, 64 140 / 146, 128 187 / 197, 256 320 /
@@ -871,7 +954,8 @@ static hipError_t dispatch_lsm(hipStream_t stream, const float* x, float* out, c
         // Plain log-softmax only: measured 2-3 % faster there (0.506 -> 0.493 ms at c4), slower for the fused
         // gather (its one-lane-per-row mapping phase wants all rows of the tile in ONE wave: 0.52 -> 0.556 ms)
         // and for the fused backward (+15 us).
-        const bool wp = (L <= 16) && !no_wp && MODE == LSM_NORM;
+        static const bool wp_fused = getenv("RNNT_LSM_WP_FUSED") != nullptr;      // (A/B: the wave-private form in the fused modes)
+        const bool wp = (L <= 16) && !no_wp && (MODE == LSM_NORM || wp_fused);
         if (wp) R = rpp;
         size_t lds = (size_t)R * V * sizeof(float) + (GATHER ? (size_t)R * sizeof(float2) : 0);
 #ifdef RNNT_LG_PROBE      // probe: fewer resident workgroups per CU (LDS the kernel does not use)
@@ -1311,20 +1395,24 @@ k_from_diagonal(const float* __restrict__ a, const float* __restrict__ b, float2
     const int ul = threadIdx.x & (TD - 1), tl0 = threadIdx.x >> 5;
     const int u = u0 + ul;
     const size_t nbase = (size_t)n * T * U;
+    // LOADS FIRST (round 5: under their conditions the eight diagonals of a thread were eight memory round trips, one
+    // after the other).  Every diagonal is loaded, at tile and lattice coordinates clamped into range -- a clamped slot
+    // receives the value of the cell it stands for, so the LDS writes need no condition either.
+    constexpr int ND = (TT + TD + 7) / 8;
+    float2 pr[ND];
+    int tls[ND];
+    const int uc = min(u, U - 1);
 #pragma unroll
-    for (int k = 0; k < (TT + TD + 7) / 8; ++k) {
-        const int d = tl0 + 8 * k;
-        const int tl = d - ul;
-        if (d < TT + TD - 1 && tl >= 0 && tl < TT) {
-            const int t = t0 + tl;
-            if (t < T && u < U) {
-                int r = t + u;
-                r = r >= T ? r % T : r;
-                const size_t at = nbase + (size_t)r * U + u;
-                tile[tl][ul] = SPLIT ? make_float2(a[at], b[at]) : reinterpret_cast<const float2*>(a)[at];
-            }
-        }
+    for (int k = 0; k < ND; ++k) {
+        tls[k] = min(max(tl0 + 8 * k - ul, 0), TT - 1);
+        const int t = min(t0 + tls[k], T - 1);
+        int r = t + uc;
+        r = r >= T ? r % T : r;
+        const size_t at = nbase + (size_t)r * U + uc;
+        pr[k] = SPLIT ? make_float2(a[at], b[at]) : reinterpret_cast<const float2*>(a)[at];
     }
+#pragma unroll
+    for (int k = 0; k < ND; ++k) tile[tls[k]][ul] = pr[k];
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < TT / 8; ++k) {
@@ -1619,12 +1707,34 @@ k_turn_compact32(const float2* __restrict__ src, const float* __restrict__ sa, c
             }
         }
     };
+    // The LOAD side of either direction is written out loads-first (round 5; see k_to_diagonal / k_from_diagonal: all of
+    // a thread's loads issued before the first LDS write, at coordinates clamped into the tile and the utterance -- a
+    // clamped slot receives the value of the cell it stands for); the store side keeps its conditions.
+    const int uc = min(u, U - 1);
     if constexpr (TO_DIAGONAL) {
-        by_frames([&](int tl, size_t at) { tile[tl][ul] = src[at]; });
+        constexpr int NK = TD / 8;
+        float2 pr[NK];
+#pragma unroll
+        for (int k = 0; k < NK; ++k) pr[k] = src[nbase + (size_t)min(t0 + tl0 + 8 * k, T - 1) * U + uc];
+#pragma unroll
+        for (int k = 0; k < NK; ++k) tile[tl0 + 8 * k][ul] = pr[k];
         __syncthreads();
         by_diagonals([&](int tl, size_t at) { dst[at] = tile[tl][ul]; });
     } else {
-        by_diagonals([&](int tl, size_t at) { tile[tl][ul] = make_float2(sa[at], sb[at]); });
+        constexpr int ND = (2 * TD) / 8;
+        float2 pr[ND];
+        int tls[ND];
+#pragma unroll
+        for (int k = 0; k < ND; ++k) {
+            tls[k] = min(max(tl0 + 8 * k - ul, 0), TD - 1);
+            const int t = min(t0 + tls[k], T - 1);
+            int r = t + uc;
+            r = r >= T ? r % T : r;
+            const size_t at = nbase + (size_t)r * U + uc;
+            pr[k] = make_float2(sa[at], sb[at]);
+        }
+#pragma unroll
+        for (int k = 0; k < ND; ++k) tile[tls[k]][ul] = pr[k];
         __syncthreads();
         by_frames([&](int tl, size_t at) { dst[at] = tile[tl][ul]; });
     }
