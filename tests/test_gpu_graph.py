@@ -231,3 +231,11 @@ def test_compact_with_launch_bounds_is_captured_and_replays():
     assert torch.isnan(c).all() and not g.any()
     c, g = run(xs, ys[:-1].contiguous(), xn, yn, max_frames=Tb, max_labels=Ub)
     assert torch.isnan(c).all() and not g.any()
+    # no rows at all against lengths that ask for some (STU == 0, N > 0): refused like any other mismatch -- NaN costs,
+    # not whatever the costs buffer held (api.hip: the bounded entry fills them before it returns)
+    from warp_rnnt_amd import ops
+    empty = torch.empty((0, V), device=dev)
+    c, g, _ = ops.loss_compact(empty, ys, xn, yn, max_frames=Tb, max_labels=Ub)
+    torch.cuda.synchronize()
+    assert c.shape == (3,) and torch.isnan(c).all()
+    assert g is None or g.numel() == 0

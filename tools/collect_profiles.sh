@@ -3,7 +3,7 @@
 # Copy the summaries into profiles/ afterwards with `python tools/summarise_profiles.py $TAG`.
 #   --pmc passes are separate from each other and never combined with other trace domains.
 set -u
-TAG=${1:-r04}
+TAG=${1:-r05}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
@@ -51,6 +51,11 @@ RNNT_PARITY_TABLE=$OUT/parity_errors.json RNNT_PARITY_BUILD="shipped" python -m 
 #  within 5e-4 of the shipped log-domain route at every size)
 # lattice kernels alone: probability domain, log domain on one workgroup per sweep / per column block
 python tools/lattice_routes.py > $OUT/lattice_routes.txt 2>&1
+# the yardsticks: copy and read-only streams of the part; the in-place log-softmax against an in-place copy at c5's V from 2 GB
+# to 130 GB; the N=128 single-GPU anchor of the strong-scaling line
+tools/ubench/copy_rate > $OUT/ubench_copy_rate.txt 2>&1
+LSM_COPY=1 LSM_INPLACE=1 python tools/lsm_rate.py 10000:1.92 10000:16 10000:64 10000:130 2>&1 | grep -v amdgpu > $OUT/lsm_rate_by_size.txt
+python $R/bench.py --config c4 --global-batch 128 --no-cpu-baseline --steps 20 > $OUT/bench_c4_n128.json 2>> $OUT/bench.err
 # the reference-named C entry points the way the reference's binding calls them
 python tools/cabi_probe.py c2 c4 2>&1 | grep -v amdgpu > $OUT/cabi_probe.txt
 # interval-by-interval timeline of the distributed log-domain kernel (diagnostics build, if it travelled)

@@ -10,7 +10,7 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-TAG = sys.argv[1] if len(sys.argv) > 1 else "r04"
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r05"
 SRC = os.path.join(ROOT, "gpurun_out", TAG)
 DST = os.path.join(ROOT, "profiles")
 
@@ -65,8 +65,8 @@ def main():
     for name in ("parity_errors.json", "lattice_probe.txt", "lattice_routes.txt", "cabi_probe.txt", "wd_trace_c4.txt",
                  "shape_map.md", "bench_c4_pd_lattice.json", "ubench_pd_steps.txt", "host_overhead.txt",
                  "bench_c4_logdomain_lattice.json", "bench_c4_rccl_group.json", "bench_c4_cold_start.json",
-                 "graph_probe.txt",
-                 "ubench_gather_variants.txt"):
+                 "graph_probe.txt", "lsm_rate_by_size.txt", "bench_c4_n128.json", "ubench_copy_rate.txt",
+                 "compact_host_probe.txt", "ubench_gather_variants.txt"):
         if os.path.exists(os.path.join(SRC, name)):
             shutil.copy(os.path.join(SRC, name), os.path.join(DST, f"{TAG}_" + name))
     # HBM traffic of the dominant kernel, per launch (FETCH_SIZE doubled for wide coalesced reads)
@@ -75,7 +75,7 @@ def main():
                      "WRITE_SIZE (separate passes, profiles/%s_rocprof_c{3,4}_pmc_hbm.csv); FETCH_SIZE doubled for "
                      "wide coalesced reads as MI355X_MICROARCH.md (HBM) prescribes" % TAG}
     for cfg, table, pats in (("c4", agg, ("k_lsm_regs<", "k_lsm_small<4,0,")), ("c3", agg3, ("k_lsm_large<0,",)),
-                             ("c4_lattice_wd", agg, ("wd::k_lattice_wd<",))):
+                             ("c4_lattice_wd", agg, ("::k_lattice_wd<",))):
         def pick(counter):
             ks = [k for k in table if any(k[0].replace(" ", "").find(pat) >= 0 for pat in pats) and k[1] == counter]
             return (ks[0][0], sum(table[ks[0]]) / len(table[ks[0]])) if ks else (None, None)

@@ -1364,6 +1364,10 @@ static hipError_t launch_to_diagonal(hipStream_t stream, const float* src, const
     return launch_to_diagonal_tt<TT>(stream, src, labels, ws2, N, T, U, V, blank, dense);
 }
 
+// (Round 5 tried the dense gather as a coalesced STREAM for V <= 64, where the two dwords per row touch nearly every
+//  128-byte line anyway: the LDS-staged log-softmax kernel without its arithmetic, pairs picked out of the staged tile.
+//  Bit-identical, and slower: c4 274 us against 250 for k_to_diagonal in the same runs, loss path 0.403 vs 0.384 ms
+//  -- a stream pays for all 1.44 GB, the scattered requests for the ~0.9 of the lines they touch.)
 hipError_t launch_gather(hipStream_t stream, const float* log_probs, const int* labels, float* out2,
                          int N, int T, int U, int V, int blank, bool skewed) {
     const size_t cells = (size_t)N * T * U;
