@@ -12,7 +12,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 TAG = sys.argv[1] if len(sys.argv) > 1 else "r05"
 SRC = os.path.join(ROOT, "gpurun_out", TAG)
-DST = os.path.join(ROOT, "profiles")
+DST = os.environ.get("PROFILES_DST") or os.path.join(ROOT, "profiles")      # (PROFILES_DST: summarise on the GPU box, into gpurun_out)
 
 
 def pmc_summary(dirs, out):
@@ -84,7 +84,7 @@ def main():
             doc[cfg] = {"kernel": kname, "fetch_size_kib": f_kib, "write_size_kib": w_kib,
                         "traffic_bytes": f_kib * 2048 + w_kib * 1024,
                         "source": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/collect_profiles.sh {TAG} "
-                                  f"(profiles/{TAG}_rocprof_{cfg}_pmc_hbm.csv)"}
+                                  f"(profiles/{TAG}_rocprof_{cfg[:2]}_pmc_hbm.csv)"}
     # the gather kernel of the loss entry (sparse dword reads: the counter tallies 64 B per request while the memory
     # system moves the whole 128-byte line -- profiles/<tag>_rocprof_probe_fetch_size.csv, the stride probes of
     # tools/ubench/gather_variants.hip run as long as a full read -- so FETCH_SIZE is doubled here too)
