@@ -1,6 +1,6 @@
 #!/bin/bash
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-OUT=$R/gpurun_out/r05fuzz
+OUT=$R/gpurun_out/fuzz_soak
 mkdir -p $OUT
 cd $R
 (echo "python tools/fuzz_parity.py --seconds 150 --seed 71"; timeout 400 python tools/fuzz_parity.py --seconds 150 --seed 71 2>&1 | grep -v amdgpu | tail -3) > $OUT/a.txt
