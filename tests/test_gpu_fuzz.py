@@ -23,3 +23,19 @@ def test_random_cases_against_the_oracle(route, seed):
                           str(seed)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
     text = out.stdout.decode()
     assert out.returncode == 0 and "fuzz ok:" in text, text[-3000:]
+
+
+@pytest.mark.parametrize("kernel", ["", "wl"])
+def test_three_processes_on_one_gpu_get_the_same_bits_every_launch(kernel):
+    """tools/wd_soak.py: three processes launch the loss entry back to back on long lattices at the same time and compare
+    every launch with their first, bit for bit.  This is the test that found what no single-process test could: the
+    hand-written lattice blocks with reloads left in flight across the barrier (round 5) gave wrong costs in 1-3 % of
+    the launches under this load and never otherwise (csrc/lattice_step.h, wait_lds).  Default routes (k_lattice_wd with
+    its L2 hand-over; lost hand-overs may be redone, the bits must not change) and k_lattice_wl pinned."""
+    env = dict(os.environ)
+    if kernel:
+        env["RNNT_LOGDOMAIN_KERNEL"] = kernel
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "wd_soak.py"), "--seconds", "8", "--procs", "3"],
+                         env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    text = out.stdout.decode()
+    assert out.returncode == 0 and text.count("results differing from the first launch: 0;") == 3, text[-3000:]

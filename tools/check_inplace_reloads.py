@@ -7,8 +7,9 @@ does not count.  The data lands some hundred cycles later; the only thing that m
 `s_waitcnt lgkmcnt(0)` in front of the block's barrier.  Nothing may read or write those registers in between -- and
 the one who could is the compiler (a register copy at a loop head, a spill, a reuse as a temporary), silently.
 
-Since round 5 the hand-written blocks even leave their last reloads in flight ACROSS the barrier (`s_waitcnt lgkmcnt(2)`
-instead of `(0)`) and retire them with a counted wait half-way through the next block.
+(Round 5 tried leaving the last reloads in flight ACROSS the barrier with counted waits: this script found nothing wrong
+with it and neither did any test -- tools/wd_soak.py with three processes on one GPU did: lattice_step.h.  The check is
+necessary, not sufficient.)
 
 This script compiles lattice_wd.hip for gfx950 with -save-temps (hipcc cross-compiles, no GPU needed) and walks the
 generated ISA of every lattice kernel with the wave's LDS operations modelled as the in-order queue they are

@@ -354,9 +354,8 @@ __device__ __forceinline__ void sweep(const LatticeArgs& a, const Item it, const
                 // the value stores and the in-place reloads of the block (inline assembly, which no fence of the compiler's
                 // counts) have to be complete: one explicit wait, with a "memory" clobber that also keeps the compiler's own
                 // LDS accesses on their side of the barrier
-                // (the hand-written blocks leave the reloads the next block needs last in flight: lattice_step.h)
-                if constexpr (MODE == ws::BLOCK_MASKED) ws::wait_lds();
-                else ws::wait_lds_but<ws::block_tail_in_flight<HAS_LEFT>()>();
+                // (zero, not a count: lattice_step.h on why nothing stays in flight across the barrier)
+                ws::wait_lds();
                 __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
             }
