@@ -49,8 +49,8 @@ SHAPES = [(3, 37, 70, True), (2, 5, 130, False), (4, 200, 65, True), (2, 150, 64
           (2, 700, 257, False), (300, 40, 130, True),
           # one column block per sweep: the plain launch (no rings, no queue, no redo kernel behind)
           (300, 40, 33, True), (3, 5, 20, True), (2, 1, 30, False), (130, 200, 64, True), (3, 100, 1, False),
-          # from 1024 frames of launch bound on the column-block kernel works in blocks of 16 diagonals (its second
-          # instantiation, csrc/lattice_wd_body.h): lone, two and five column blocks, ragged and not, U - 1 on a block edge
+          # long sweeps: lone, two and five column blocks, ragged and not, U - 1 on a block edge (also run on the kernel's
+          # second instantiation, blocks of 16 diagonals, by test_blocks_of_sixteen_diagonals_same_bits below)
           (3, 1030, 40, True), (2, 1100, 70, True), (2, 1200, 300, False), (3, 1024, 129, True), (2, 1500, 17, False)]
 
 
@@ -203,3 +203,38 @@ def test_compact_layout_same_bits(N, T, U, V):
             warp_rnnt_amd.set_logdomain_kernel(old_k)
     assert torch.equal(out["ws"][0], out["wd"][0]) and torch.equal(out["ws"][1], out["wd"][1])
     assert torch.equal(out["ws"][0], out["wl"][0]) and torch.equal(out["ws"][1], out["wl"][1])
+
+
+def test_blocks_of_sixteen_diagonals_same_bits():
+    """csrc/lattice_wd_body.h is compiled twice; the instantiation with blocks of 16 diagonals is opt-in since the end of
+    round 5 (RNNT_WD_K16_FROM_T; csrc/lattice_wd.hip says why).  It has to give the bits of the single-workgroup kernel
+    like the other one: the long shapes of SHAPES in a subprocess with the knob set."""
+    code = r'''
+import sys
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import numpy as np, torch
+import warp_rnnt_amd, oracle
+from helpers import make_case, np_log_softmax32
+from warp_rnnt_amd import ops
+dev = torch.device("cuda:0")
+L = ops._lib.load()
+for (N, T, U, ragged) in [(3, 1030, 40, True), (2, 1100, 70, True), (2, 1200, 300, False), (3, 1024, 129, True), (2, 1500, 17, False)]:
+    logits, labels, xn, yn = make_case(1000 + N + T + U, N, T, U, 6, ragged=ragged)
+    lp2 = torch.tensor(oracle.gather_f32(np_log_softmax32(logits), labels, 0), device=dev)
+    txn, tyn = torch.tensor(xn, device=dev), torch.tensor(yn, device=dev)
+    res = {}
+    for k in ("ws", "wd"):
+        warp_rnnt_amd.set_lattice("logdomain"); warp_rnnt_amd.set_logdomain_kernel(k)
+        ws = torch.empty((L.rnnt_amd_workspace_size(N, T, U),), dtype=torch.uint8, device=dev)
+        costs = torch.empty((N,), device=dev); grads = torch.empty((N, T, U, 2), device=dev)
+        st = L.rnnt_amd_loss(torch.cuda.current_stream().cuda_stream, ws.data_ptr(), 1, lp2.data_ptr(), None,
+                             txn.data_ptr(), tyn.data_ptr(), costs.data_ptr(), grads.data_ptr(), 0, N, T, U, 2, 0, 0.01)
+        assert st == 0
+        torch.cuda.synchronize()
+        res[k] = (costs, grads)
+    assert torch.equal(res["ws"][0], res["wd"][0]) and torch.equal(res["ws"][1], res["wd"][1]), (N, T, U)
+print("K16_SAME_BITS_OK")
+''' % (os.path.dirname(HERE), HERE)
+    env = dict(os.environ, RNNT_WD_K16_FROM_T="1024")
+    out = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+    assert out.returncode == 0 and b"K16_SAME_BITS_OK" in out.stdout, out.stdout.decode()[-3000:]

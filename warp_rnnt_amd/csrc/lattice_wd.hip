@@ -64,12 +64,17 @@ namespace rnnt {
 #undef RNNT_WD_NS
 #undef RNNT_WD_KK
 
-// Blocks of 16 diagonals from this many frames on (the launch bound T, so that a batch makes one choice): measured
-// (tools/lattice_routes.py, us per alpha+beta launch, 8 / 16: N=16, T=1500: U=64 68.7 / 64.5, U=300 102.4 / 100.2, U=512
-// 123.8 / 122.6; T=700, U=100 48.2 / 48.8; T=150, U=40 13.2 / 13.7).  RNNT_WD_K16_FROM_T overrides, for A/B runs and for
-// the trace tool.
+// Blocks of 16 diagonals: measured faster from ~1000 frames on (tools/lattice_routes.py, us per alpha+beta launch, 8 / 16:
+// N=16, T=1500: U=64 68.7 / 64.5, U=300 102.4 / 100.2, U=512 123.8 / 122.6; T=700, U=100 48.2 / 48.8; T=150, U=40 13.2 / 13.7)
+// and for most of round 5 the choice from launch bound T >= 1024 on.  NOT THE DEFAULT ANY MORE: with three processes
+// sharing the GPU (tools/wd_soak.py) the 16-diagonal instantiation, and only it, showed hand-overs declared lost (10-20
+// per 100 000 launches -- repaired by the kernel behind, as designed) and, once in 40 000 ... 170 000 launches, a few
+// wrong values in a stored plane with no flag raised (profiles/r05_wd_soak.txt: the last column block of a beta sweep,
+// column u = 0); the 8-diagonal instantiation: none of either in 1.5 M launches under the same load.  The cause was not
+// found in the time there was.  RNNT_WD_K16_FROM_T=<T> turns the 16-diagonal blocks on from that launch bound T (for
+// whoever looks for it; same bits when nothing goes wrong).
 static int wd_block_diagonals(int T) {
-    static const int from_t = getenv("RNNT_WD_K16_FROM_T") ? atoi(getenv("RNNT_WD_K16_FROM_T")) : 1024;
+    static const int from_t = getenv("RNNT_WD_K16_FROM_T") ? atoi(getenv("RNNT_WD_K16_FROM_T")) : 0x7fffffff;
     return T >= from_t ? 16 : 8;
 }
 

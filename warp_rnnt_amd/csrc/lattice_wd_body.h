@@ -85,7 +85,11 @@ __device__ __forceinline__ i32x4 make_rsrc(const void* p, unsigned bytes) {
 // there: nothing the compiler generates for these waves reads M0.
 __device__ __forceinline__ void dma16(const int voff, const i32x4 rs, const int soff, unsigned lds) {
     lds = __builtin_amdgcn_readfirstlane(lds);
+#ifdef RNNT_WD_DMA_ALL_SC1
+    asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen sc1 lds" ::"v"(voff), "s"(rs), "s"(soff), "s"(lds) : "memory");
+#else
     asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds" ::"v"(voff), "s"(rs), "s"(soff), "s"(lds) : "memory");
+#endif
 }
 __device__ __forceinline__ void dma16_agent(const int voff, const i32x4 rs, unsigned lds) {   // agent scope (sc1)
     lds = __builtin_amdgcn_readfirstlane(lds);
