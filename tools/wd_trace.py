@@ -37,7 +37,7 @@ costs = torch.empty((N,), device=dev)
 grads = torch.empty((N, T, U, 2), device=dev)
 ws = torch.zeros((L.rnnt_amd_workspace_size(N, T, U),), dtype=torch.uint8, device=dev)
 s = torch.cuda.current_stream().cuda_stream
-K = 16 if T >= int(os.environ.get("RNNT_WD_K16_FROM_T", "1024")) else 8     # (csrc/lattice_wd.hip: wd_block_diagonals)
+K = 16 if T >= int(os.environ.get("RNNT_WD_K16_FROM_T", str(2**31 - 1))) else 8     # (csrc/lattice_wd.hip: wd_block_diagonals)
 nA = (U + 63) // 64
 pitch = ((T + U - 1 + K - 1) // K + 2) * K
 slots = (T + U - 1) // K + 24
