@@ -12,10 +12,9 @@ with it and neither did any test -- tools/wd_soak.py with three processes on one
 necessary, not sufficient.)
 
 This script compiles lattice_wd.hip for gfx950 with -save-temps (hipcc cross-compiles, no GPU needed) and walks the
-generated ISA of every lattice kernel with the wave's LDS operations modelled as the in-order queue they are
-(`lgkmcnt(N)` retires all but the N youngest): any instruction that touches a register whose reload is still in the
-queue is reported.  One path per kernel: straight-line code, fall-through edges, unconditional branches followed once --
-which takes the walk around every loop body twice, the second time with what the first left in flight.
+generated ISA of every lattice kernel as a forward data-flow problem over ALL edges of its control-flow graph: the set of
+registers that may have a reload in flight, emptied only by a full `s_waitcnt lgkmcnt(0)`; any instruction that touches a
+register of the set is reported.
 
     python tools/check_inplace_reloads.py [file.s]        exit status 1 on a violation
 """
@@ -58,86 +57,83 @@ def compile_to_asm(src, extra=()):
 def check(path):
     """Returns (kernels seen, in-place reloads seen, [violations]).
 
-    Walks every lattice kernel along ONE path: straight-line code, the fall-through edge of conditional branches, and
-    unconditional branches followed to their label (each branch site once, which takes the walk around every loop body
-    a second time -- with whatever the first pass left in flight).  The wave's LDS operations are modelled as the
-    in-order queue they are: `s_waitcnt lgkmcnt(N)` retires all but the N youngest, and a register is "in flight" from
-    its reload until that reload retires."""
+    Forward data flow over the control-flow graph of every lattice kernel -- ALL edges, to a fixed point: the state is the
+    set of registers an in-place reload may still have in flight; an inline-assembly `ds_read*` adds its destination, a
+    full `s_waitcnt lgkmcnt(0)` empties the set (a counted wait retires nothing here: the kernels' own rule is that only
+    the zero wait in front of the block barrier makes the registers valid), and any instruction that reads or writes a
+    register of the set -- or a reload whose ADDRESS register is in it -- is a violation.  (Until the end of round 5 this
+    walked one path per kernel with the LDS queue modelled in order; that missed whatever sits on the other edges.)"""
     lines = open(path).read().split("\n")
-    # function extents and labels
     funcs, cur = [], None
     for i, line in enumerate(lines):
         m = re.match(r"^(_Z\w+):", line)
         if m:
-            cur = [m.group(1), i, None, {}]
+            cur = [m.group(1), i, None]
             funcs.append(cur)
-        elif cur is not None and cur[2] is None:
-            lm = re.match(r"^(\.LBB\w+):", line)
-            if lm:
-                cur[3][lm.group(1)] = i
-            if re.match(r"^\s*s_endpgm", line):
-                cur[2] = i
+        elif cur is not None and cur[2] is None and re.match(r"^\s*s_endpgm", line):
+            cur[2] = i
     kernels, reloads, bad = 0, 0, []
-    for fn, start, end, labels in funcs:
+    for fn, start, end in funcs:
         if "k_lattice" not in fn or end is None:
             continue
         kernels += 1
-        fifo = []            # [(line, regs-or-None)]: outstanding LDS operations, oldest first; regs for in-place reloads
-        followed, seen_reload_lines, reported = set(), set(), set()
-        i, in_asm, steps = start + 1, False, 0
-        while i <= end and steps < 400000:
-            steps += 1
+        # instructions of the kernel: (line number, text, in inline assembly?)
+        insts, labels, in_asm = [], {}, False
+        for i in range(start + 1, end + 1):
             raw = lines[i]
-            ln = i + 1
             st = raw.strip()
             if st.startswith(";;#ASMSTART"):
-                in_asm = True; i += 1; continue
+                in_asm = True; continue
             if st.startswith(";;#ASMEND"):
-                in_asm = False; i += 1; continue
-            s = raw.split(";")[0].rstrip()
-            if not s.strip() or s.lstrip().startswith(".") or re.match(r"^\.?\w+:", s.strip()):
-                i += 1; continue
-            if re.match(r"^\s*s_endpgm", s):
-                break
-            w = re.match(r"^\s*s_waitcnt\b(.*)", s)
-            if w:
-                m = re.search(r"lgkmcnt\((\d+)\)", w.group(1))
-                if m:
-                    keep = int(m.group(1))
-                    fifo = fifo[len(fifo) - keep:] if keep else []
-                elif re.match(r"^\s*s_waitcnt\s+0\s*$", s):
-                    fifo = []
-                i += 1; continue
-            b = re.match(r"^\s*s_branch\s+(\.LBB\w+)", s)
-            if b:
-                if i in followed or b.group(1) not in labels:
-                    fifo = []      # this path has been walked: go on behind the branch as a fresh one
-                    i += 1
-                else:
-                    followed.add(i)
-                    i = labels[b.group(1)]
+                in_asm = False; continue
+            lm = re.match(r"^(\.LBB\w+):", raw)
+            if lm:
+                labels[lm.group(1)] = len(insts); continue
+            t = raw.split(";")[0].rstrip()
+            if not t.strip() or t.lstrip().startswith(".") or re.match(r"^\.?\w+:", t.strip()):
                 continue
-            pending = set()
-            for _, regs in fifo:
-                if regs:
-                    pending |= regs
-            r = RELOAD.match(s) if in_asm else None
-            touched = regs_of(s)
-            if r:
-                dst, addr = regs_of(r.group(2)), regs_of(r.group(3))
-                hit = addr & pending
-                if hit and ln not in reported:
-                    reported.add(ln); bad.append((fn, ln, s.strip(), sorted(hit)))
-                if ln not in seen_reload_lines:
-                    seen_reload_lines.add(ln); reloads += 1
-                fifo.append((ln, dst))
-                i += 1; continue
-            hit = touched & pending
-            if hit and ln not in reported:
-                reported.add(ln); bad.append((fn, ln, s.strip(), sorted(hit)))
-            if re.match(r"^\s*(ds_|s_load|s_buffer_load)", s):
-                fifo.append((ln, None))     # any other operation of the same counter: in the queue, nothing to protect
-            i += 1
+            insts.append((i + 1, t.strip(), in_asm))
+        n = len(insts)
+        succ = [[] for _ in range(n)]
+        for k, (_, t, _) in enumerate(insts):
+            b = re.match(r"^s_c?branch\w*\s+(\.LBB\w+)", t)
+            if t.startswith("s_endpgm"):
+                continue
+            if b and b.group(1) in labels and labels[b.group(1)] < n:
+                succ[k].append(labels[b.group(1)])
+            if not t.startswith("s_branch") and k + 1 < n:
+                succ[k].append(k + 1)
+        reloads += sum(1 for (_, t, a) in insts if a and RELOAD.match("\t" + t))
+        state_in = [None] * n           # set of registers possibly in flight on entry
+        state_in[0] = frozenset()
+        work = [0]
+        reported = set()
+        while work:
+            k = work.pop()
+            ln, t, a = insts[k]
+            inset = state_in[k]
+            out = inset
+            w = re.match(r"^s_waitcnt\b(.*)", t)
+            if w:
+                if re.search(r"lgkmcnt\(0\)", w.group(1)) or re.match(r"^\s*0\s*$", w.group(1)):
+                    out = frozenset()
+            else:
+                r = RELOAD.match("\t" + t) if a else None
+                if r:
+                    dst, addr = regs_of(r.group(2)), regs_of(r.group(3))
+                    hit = (addr | dst) & inset
+                    if hit and ln not in reported:
+                        reported.add(ln); bad.append((fn, ln, t, sorted(hit)))
+                    out = inset | dst
+                else:
+                    hit = regs_of(t) & inset
+                    if hit and ln not in reported:
+                        reported.add(ln); bad.append((fn, ln, t, sorted(hit)))
+            for s_ in succ[k]:
+                merged = out if state_in[s_] is None else (state_in[s_] | out)
+                if merged != state_in[s_]:
+                    state_in[s_] = merged
+                    work.append(s_)
     return kernels, reloads, bad
 
 

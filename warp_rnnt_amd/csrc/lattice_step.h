@@ -223,11 +223,14 @@ __device__ __forceinline__ void wait_lds() { asm volatile("s_waitcnt lgkmcnt(0)"
 // lgkmcnt(N), N = the LDS operations issued since: ~1 us at c4, the same bits in every test, in the fuzz runs and in
 // 260 000 back-to-back launches of a lone process -- and WRONG RESULTS in 1-3 % of the launches as soon as two other
 // processes kept the GPU busy (tools/wd_soak.py --procs 3: costs off by 0.1 ... 1, no flag raised; the same build with
-// zeros in the two waits: none in 360 000).  Why is not established: the counts are right if a wave's LDS operations
-// retire in issue order (which the compiler's own counted waits assume as well), and the static checker finds no
-// instruction that touches a register in flight on the paths it walks.  What is established is that reloads in flight
-// across s_barrier plus a counted wait are not safe on this part under load, and that lgkmcnt(0) in front of the barrier
-// is.  So: zero, always.  tools/wd_soak.py is the regression test (tests/test_gpu_fuzz.py).
+// zeros in the two waits: none in 360 000).  The mechanism, as far as it was traced: a register that an inline-assembly
+// load writes is, to the compiler, free again the moment its C++ variable dies -- it hands it to something else while the
+// load is still on its way, and a load that lands late (an LDS kept busy by other processes' workgroups) overwrites the
+// new tenant.  Reloads in flight across the barrier multiply the places where that can happen; the storer's dry run
+// without its end-of-block wait was one more (lattice_wd_body.h: one_block).  THE RULE: a register written by an
+// inline-assembly load stays an operand of the code until an explicit wait has retired the load, and every block --
+// the dry ones too -- ends with lgkmcnt(0).  tools/check_inplace_reloads.py checks it over every edge of the control-flow
+// graph; tools/wd_soak.py is the regression test (tests/test_gpu_fuzz.py).
 template <int N> __device__ __forceinline__ void wait_lds_but() { static_assert(N == 0, "counted LDS waits are not safe: see above"); wait_lds(); }
 template <bool SEEDED> constexpr int block_tail_in_flight() { return 0; }
 

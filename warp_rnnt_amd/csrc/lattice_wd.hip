@@ -66,13 +66,12 @@ namespace rnnt {
 
 // Blocks of 16 diagonals: measured faster from ~1000 frames on (tools/lattice_routes.py, us per alpha+beta launch, 8 / 16:
 // N=16, T=1500: U=64 68.7 / 64.5, U=300 102.4 / 100.2, U=512 123.8 / 122.6; T=700, U=100 48.2 / 48.8; T=150, U=40 13.2 / 13.7)
-// and for most of round 5 the choice from launch bound T >= 1024 on.  NOT THE DEFAULT ANY MORE: with three processes
-// sharing the GPU (tools/wd_soak.py) the 16-diagonal instantiation, and only it, showed hand-overs declared lost (10-20
-// per 100 000 launches -- repaired by the kernel behind, as designed) and, once in 40 000 ... 170 000 launches, a few
-// wrong values in a stored plane with no flag raised (profiles/r05_wd_soak.txt: the last column block of a beta sweep,
-// column u = 0); the 8-diagonal instantiation: none of either in 1.5 M launches under the same load.  The cause was not
-// found in the time there was.  RNNT_WD_K16_FROM_T=<T> turns the 16-diagonal blocks on from that launch bound T (for
-// whoever looks for it; same bits when nothing goes wrong).
+// and for most of round 5 the choice from launch bound T >= 1024 on.  Not the default: with three processes sharing the
+// GPU (tools/wd_soak.py) this instantiation was where the storer's dry run -- reloads left in flight into registers the
+// compiler reused (lattice_wd_body.h: one_block) -- showed as lost hand-overs and rare wrong plane values, so it was
+// switched off while the cause was unknown, and the round's profiles are of the 8-diagonal default.  With the cause fixed
+// it ran 340 000 launches clean under the same load; it stays opt-in until somebody re-measures:
+// RNNT_WD_K16_FROM_T=<T> turns the 16-diagonal blocks on from that launch bound T (same bits).
 static int wd_block_diagonals(int T) {
     static const int from_t = getenv("RNNT_WD_K16_FROM_T") ? atoi(getenv("RNNT_WD_K16_FROM_T")) : 0x7fffffff;
     return T >= from_t ? 16 : 8;

@@ -354,12 +354,20 @@ __device__ __forceinline__ void sweep(const LatticeArgs& a, const Item it, const
             ++lb;
             prepare_block();
             asm volatile("" : "+v"(nsrc), "+s"(nseed), "+v"(vslot));   // (worked out HERE, not behind the barrier)
+            // The value stores and the in-place reloads of the block (inline assembly, which no fence of the compiler's counts)
+            // have to be complete: one explicit wait, with a "memory" clobber that also keeps the compiler's own LDS
+            // accesses on their side of the barrier.  Zero, not a count (lattice_step.h) -- and IN THE DRY RUN TOO.  Until
+            // the end of round 5 the storer's dry blocks skipped this wait with the barrier, and went on into the storer's
+            // own code with their last reloads still on the way to registers that were dead by then and that the compiler
+            // handed out again at once -- to the storer's store offsets, among others.  A reload that landed late (an LDS
+            // kept busy by other processes' workgroups) overwrote them: a lane's values stored into another column for
+            // the rest of the sweep (zeros from the not yet filled tile = column 0), granules published to addresses
+            // nobody polls (a hand-over "lost" after a second of polling).  tools/check_inplace_reloads.py, once it
+            // followed every edge of the control-flow graph instead of one path, pointed at it; tools/wd_soak.py had
+            // shown the symptoms (profiles/r05_wd_soak.txt: the blocks of 16 diagonals, whose twelve reloads per dry block
+            // happened to share registers with the offsets).
+            ws::wait_lds();
             if (!dry) {
-                // the value stores and the in-place reloads of the block (inline assembly, which no fence of the compiler's
-                // counts) have to be complete: one explicit wait, with a "memory" clobber that also keeps the compiler's own
-                // LDS accesses on their side of the barrier
-                // (zero, not a count: lattice_step.h on why nothing stays in flight across the barrier)
-                ws::wait_lds();
                 __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
             }
