@@ -25,17 +25,20 @@ def test_random_cases_against_the_oracle(route, seed):
     assert out.returncode == 0 and "fuzz ok:" in text, text[-3000:]
 
 
-@pytest.mark.parametrize("kernel", ["", "wl"])
-def test_three_processes_on_one_gpu_get_the_same_bits_every_launch(kernel):
-    """tools/wd_soak.py: three processes launch the loss entry back to back on long lattices at the same time and compare
-    every launch with their first, bit for bit.  This is the test that found what no single-process test could: the
-    hand-written lattice blocks with reloads left in flight across the barrier (round 5) gave wrong costs in 1-3 % of
-    the launches under this load and never otherwise (csrc/lattice_step.h, wait_lds).  Default routes (k_lattice_wd with
-    its L2 hand-over; lost hand-overs may be redone, the bits must not change) and k_lattice_wl pinned."""
-    env = dict(os.environ)
-    if kernel:
-        env["RNNT_LOGDOMAIN_KERNEL"] = kernel
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "wd_soak.py"), "--seconds", "8", "--procs", "3"],
-                         env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+@pytest.mark.parametrize("name,env_extra", [("default", {}), ("wl", {"RNNT_LOGDOMAIN_KERNEL": "wl"}),
+                                            ("k16", {"RNNT_WD_K16_FROM_T": "1024"})])
+def test_six_processes_on_one_gpu_get_the_reference_bits_every_launch(name, env_extra):
+    """tools/wd_soak.py: six processes launch the loss entry back to back on the six-shape set at the same time (45 s each
+    leg) and compare every launch -- costs, gradients, alpha and beta planes -- bit for bit with a reference computed once
+    by the OTHER kernel (k_lattice_ws: compiler-scheduled, no in-place reloads, no hand-over through L2).  This is the load
+    that found what no single-process test could: the hand-written lattice blocks with reloads left in flight across the
+    barrier (round 5) gave wrong costs in 1-3 % of the launches under it and never otherwise, the storer's dry run without
+    its wait one wrong plane in 40 000 ... 170 000 (csrc/lattice_step.h, wait_lds).  Legs: the default routes (k_lattice_wd
+    with its L2 hand-over -- lost hand-overs may be redone, the bits must not change --, k_lattice_wl for the narrower
+    lattices, the plain launch for single column blocks), k_lattice_wl pinned wherever it fits, and the 16-diagonal blocks
+    of k_lattice_wd from T >= 1024.  The static half of the gate is in the build (warp_rnnt_amd/_isa_check.py)."""
+    env = dict(os.environ, **env_extra)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "wd_soak.py"), "--seconds", "45", "--procs", "6"],
+                         env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
     text = out.stdout.decode()
-    assert out.returncode == 0 and text.count("results differing from the first launch: 0;") == 3, text[-3000:]
+    assert out.returncode == 0 and text.count("results differing from the k_lattice_ws reference: 0;") == 6, text[-3000:]

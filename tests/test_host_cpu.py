@@ -435,6 +435,29 @@ def test_in_place_reloads_of_the_lattice_kernels_are_not_touched_before_their_wa
     assert len(chk.check(bpath)[2]) == 1
 
 
+def test_the_build_refuses_a_planted_reload_violation(monkeypatch):
+    """`_build.build()` checks the ISA of the object it is about to link (warp_rnnt_amd/_isa_check.py) and FAILS when an
+    instruction touches a register whose in-place LDS reload may still be in flight -- the family of round 5's two silent
+    wrong-answer bugs.  The `planted_violation` variant ends the hand-written blocks with `lgkmcnt(2)` instead of
+    `lgkmcnt(0)` (two reloads left in flight across the barrier: exactly the first of those bugs): build() must raise,
+    leave no object and no library behind, and the default build must be one that went through the same gate."""
+    from warp_rnnt_amd import _build, _isa_check
+    assert "lattice_wd.hip" in _build.RELOAD_CHECKED and "lattice_wd.hip" in _build.SOURCES
+    monkeypatch.setattr(_build, "SOURCES", ["lattice_wd.hip"])      # (the one translation unit with such reloads)
+    objdir = os.path.join(os.path.dirname(_build.LIB), "build_planted_violation")
+    with pytest.raises(_isa_check.ReloadCheckError, match="reload may still be in flight"):
+        _build.build(variant="planted_violation")
+    assert not os.path.exists(os.path.join(objdir, "lattice_wd.o"))
+    assert not os.path.exists(_build.variant_path("planted_violation"))
+    # ... and the shipped library's own object carries the mark of a passed check for exactly its sources and flags
+    monkeypatch.undo()
+    _build.build()
+    mark = os.path.join(os.path.dirname(_build.LIB), "build", "lattice_wd.o.reloads_ok")
+    if os.path.exists(os.path.join(os.path.dirname(_build.LIB), "build", "lattice_wd.o")):   # (built here, not shipped prebuilt)
+        with open(mark) as f, open(_build.LIB + ".fingerprint") as g:
+            assert f.read() == g.read()
+
+
 def test_package_self_test_ships_the_golden_data_and_skips_cleanly_without_a_gpu():
     """`python -m warp_rnnt.test` (pytorch_binding/README.md:76-79): the data file inside the package is the repository's
     golden file, byte for byte; on a machine without a GPU every case is skipped (there is no CPU path to fall back to)

@@ -8,6 +8,8 @@ import shutil
 import subprocess
 from concurrent.futures import ThreadPoolExecutor
 
+from . import _isa_check
+
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libwarp_rnnt_amd.so")
@@ -16,6 +18,11 @@ SOURCES = ["api.hip", "lattice.hip", "lattice_ws.hip", "lattice_wd.hip", "lattic
 HEADERS = ["common.h", "kernels.h", "lattice_step.h", "lattice_wd_body.h", "grads_cell.h",
            os.path.join("..", "..", "include", "warp_rnnt_amd.h")]
 ARCH = "gfx950"
+# Sources whose kernels refill live registers with inline-assembly LDS loads the compiler does not count (lattice_step.h):
+# the ISA of the object that ships is checked by _isa_check on EVERY build, and a violation fails the build (round 5
+# shipped two silent wrong-answer bugs of this family).  Value: (kernels, in-place reloads) the file is known to hold at
+# least -- a check that no longer finds them must not pass.
+RELOAD_CHECKED = {"lattice_wd.hip": (8, 600)}
 
 
 def _hipcc():
@@ -62,6 +69,9 @@ VARIANTS = {
     # A/B of k_lattice_wl's wave placement: six waves in column-block-major order / compute waves at raised priority
     "wl_nopad": ["-DRNNT_WL_PAD=0"],
     "wl_noprio": ["-DRNNT_WL_PRIO=0"],
+    # a build that MUST FAIL: the hand-written blocks end with two of their in-place reloads still in flight -- the bug
+    # class of round 5; tests/test_host_cpu.py checks that build() refuses it (warp_rnnt_amd/_isa_check.py)
+    "planted_violation": ["-DRNNT_PLANT_RELOAD_VIOLATION"],
 }
 
 
@@ -92,11 +102,36 @@ def build(force=False, verbose=False, extra_flags=(), variant=None):
     def compile_one(src):
         s = os.path.join(CSRC, src)
         o = os.path.join(objdir, src.replace(".hip", ".o"))
-        if force or _stale(o, [s] + hdrs):
-            cmd = [hipcc] + flags + ["-c", s, "-o", o]
+        checked = RELOAD_CHECKED.get(src)
+        ok_mark = o + ".reloads_ok"
+        if force or _stale(o, [s] + hdrs) or (checked and _read(ok_mark) != fp):
+            # (the files with hand-placed LDS reloads are compiled through their assembly text, -save-temps=obj, so that
+            #  what is checked below is what is assembled into the object -- not a second compilation's output)
+            cmd = [hipcc] + flags + (["-save-temps=obj"] if checked else []) + ["-c", s, "-o", o]
             if verbose:
                 print(" ".join(cmd), flush=True)
+            if os.path.exists(ok_mark):
+                os.remove(ok_mark)
             subprocess.check_call(cmd)
+            if checked:
+                isa = os.path.join(objdir, src.replace(".hip", "") + "-hip-amdgcn-amd-amdhsa-" + ARCH + ".s")
+                stem = os.path.join(objdir, src.replace(".hip", ""))
+                try:
+                    kernels, reloads = _isa_check.require_clean(isa, *checked)
+                except _isa_check.ReloadCheckError:
+                    os.remove(o)          # nothing links against an object that failed its check (its ISA stays, to look at)
+                    raise
+                finally:                  # (-save-temps leaves ~15 MB of intermediates per file)
+                    for f in os.listdir(objdir):
+                        full = os.path.join(objdir, f)
+                        if full.startswith(stem + "-h") and not (f.endswith(ARCH + ".s") and not os.path.exists(o)):
+                            os.remove(full)
+                    if os.path.exists(stem + ".hip-hip-amdgcn-amd-amdhsa.hipfb"):
+                        os.remove(stem + ".hip-hip-amdgcn-amd-amdhsa.hipfb")
+                if verbose:
+                    print(f"{src}: {kernels} lattice kernels, {reloads} in-place LDS reloads checked, 0 violations", flush=True)
+                with open(ok_mark, "w") as f:
+                    f.write(fp)
         return o
 
     with ThreadPoolExecutor(max_workers=len(SOURCES)) as ex:

@@ -1,0 +1,135 @@
+"""Static check of the in-place LDS reloads of the column-block lattice kernels (csrc/lattice_step.h, lattice_wd.hip),
+run by _build.build() on the ISA of the very object that goes into the library -- a violation FAILS THE BUILD.
+
+The compute wave refills the registers of a block's (blank, label) pairs and boundary seeds with the NEXT block's values
+while it is still working on the current block: `ds_read2st64_b64` / `ds_read_b128` in inline assembly, which the compiler
+does not count.  The data lands some hundred cycles later; the only thing that makes the registers valid is the
+`s_waitcnt lgkmcnt(0)` in front of the block's barrier.  Nothing may read or write those registers in between -- and
+the one who could is the compiler (a register copy at a loop head, a live-range split, a spill, a reuse as a temporary),
+silently, and differently with every compiler version or flag.  Round 5 shipped two silent wrong-answer bugs of this
+family that only a multi-process soak saw (lattice_step.h: wait_lds); round 6 made this check part of the build and saw
+it refuse a well-meant change of the wait's operand constraints (96 compiler-inserted copies of in-flight registers).
+
+The check walks the generated ISA of every lattice kernel as a forward data-flow problem over ALL edges of its
+control-flow graph: the state is the set of registers that may have a reload in flight, emptied only by a full
+`s_waitcnt lgkmcnt(0)`; any instruction that touches a register of the set is reported.  Necessary, not sufficient
+(tools/wd_soak.py is the other half).
+"""
+import re
+
+REG = re.compile(r"\bv(\d+)\b|\bv\[(\d+):(\d+)\]")
+RELOAD = re.compile(r"^\s*(ds_read2st64_b64|ds_read_b32|ds_read_b64|ds_read_b128)\s+(v\d+|v\[\d+:\d+\])\s*,\s*(v\d+)")
+
+
+class ReloadCheckError(RuntimeError):
+    """The generated ISA touches a register whose in-place reload may still be in flight (or holds no reload at all
+    where some are expected: the check would be vacuous)."""
+
+
+def regs_of(text):
+    out = set()
+    for m in REG.finditer(text):
+        if m.group(1) is not None:
+            out.add(int(m.group(1)))
+        else:
+            out.update(range(int(m.group(2)), int(m.group(3)) + 1))
+    return out
+
+
+def check(path):
+    """Returns (kernels seen, in-place reloads seen, [violations]).
+
+    Forward data flow over the control-flow graph of every lattice kernel -- ALL edges, to a fixed point: the state is the
+    set of registers an in-place reload may still have in flight; an inline-assembly `ds_read*` adds its destination, a
+    full `s_waitcnt lgkmcnt(0)` empties the set (a counted wait retires nothing here: the kernels' own rule is that only
+    the zero wait in front of the block barrier makes the registers valid), and any instruction that reads or writes a
+    register of the set -- or a reload whose ADDRESS register is in it -- is a violation.  (Until the end of round 5 this
+    walked one path per kernel with the LDS queue modelled in order; that missed whatever sits on the other edges.)"""
+    lines = open(path).read().split("\n")
+    funcs, cur = [], None
+    for i, line in enumerate(lines):
+        m = re.match(r"^(_Z\w+):", line)
+        if m:
+            cur = [m.group(1), i, None]
+            funcs.append(cur)
+        elif cur is not None and cur[2] is None and re.match(r"^\s*s_endpgm", line):
+            cur[2] = i
+    kernels, reloads, bad = 0, 0, []
+    for fn, start, end in funcs:
+        if "k_lattice" not in fn or end is None:
+            continue
+        kernels += 1
+        # instructions of the kernel: (line number, text, in inline assembly?)
+        insts, labels, in_asm = [], {}, False
+        for i in range(start + 1, end + 1):
+            raw = lines[i]
+            st = raw.strip()
+            if st.startswith(";;#ASMSTART"):
+                in_asm = True; continue
+            if st.startswith(";;#ASMEND"):
+                in_asm = False; continue
+            lm = re.match(r"^(\.LBB\w+):", raw)
+            if lm:
+                labels[lm.group(1)] = len(insts); continue
+            t = raw.split(";")[0].rstrip()
+            if not t.strip() or t.lstrip().startswith(".") or re.match(r"^\.?\w+:", t.strip()):
+                continue
+            insts.append((i + 1, t.strip(), in_asm))
+        n = len(insts)
+        succ = [[] for _ in range(n)]
+        for k, (_, t, _) in enumerate(insts):
+            b = re.match(r"^s_c?branch\w*\s+(\.LBB\w+)", t)
+            if t.startswith("s_endpgm"):
+                continue
+            if b and b.group(1) in labels and labels[b.group(1)] < n:
+                succ[k].append(labels[b.group(1)])
+            if not t.startswith("s_branch") and k + 1 < n:
+                succ[k].append(k + 1)
+        reloads += sum(1 for (_, t, a) in insts if a and RELOAD.match("\t" + t))
+        state_in = [None] * n           # set of registers possibly in flight on entry
+        state_in[0] = frozenset()
+        work = [0]
+        reported = set()
+        while work:
+            k = work.pop()
+            ln, t, a = insts[k]
+            inset = state_in[k]
+            out = inset
+            w = re.match(r"^s_waitcnt\b(.*)", t)
+            if w:
+                if re.search(r"lgkmcnt\(0\)", w.group(1)) or re.match(r"^\s*0\s*$", w.group(1)):
+                    out = frozenset()
+            else:
+                r = RELOAD.match("\t" + t) if a else None
+                if r:
+                    dst, addr = regs_of(r.group(2)), regs_of(r.group(3))
+                    hit = (addr | dst) & inset
+                    if hit and ln not in reported:
+                        reported.add(ln); bad.append((fn, ln, t, sorted(hit)))
+                    out = inset | dst
+                else:
+                    hit = regs_of(t) & inset
+                    if hit and ln not in reported:
+                        reported.add(ln); bad.append((fn, ln, t, sorted(hit)))
+            for s_ in succ[k]:
+                merged = out if state_in[s_] is None else (state_in[s_] | out)
+                if merged != state_in[s_]:
+                    state_in[s_] = merged
+                    work.append(s_)
+    return kernels, reloads, bad
+
+
+def require_clean(path, min_kernels=1, min_reloads=1):
+    """check(path), as a gate: raises ReloadCheckError on any violation, and when fewer kernels / reloads were seen than
+    the caller knows the file to hold (a pattern that stopped matching must not pass as "nothing wrong")."""
+    kernels, reloads, bad = check(path)
+    if kernels < min_kernels or reloads < min_reloads:
+        raise ReloadCheckError(f"{path}: {kernels} lattice kernels / {reloads} in-place reloads found, expected at least "
+                               f"{min_kernels} / {min_reloads}: the check no longer sees what it is there to check")
+    if bad:
+        lines = "\n".join(f"  line {ln}: `{text}` touches v{regs} while its reload is in flight   [{fn[:60]}]"
+                          for fn, ln, text, regs in bad[:12])
+        raise ReloadCheckError(f"{path}: {len(bad)} instruction(s) touch a register whose in-place LDS reload may still be "
+                               f"in flight (csrc/lattice_step.h: wait_lds) -- this build would compute wrong lattices under "
+                               f"load:\n{lines}")
+    return kernels, reloads

@@ -366,7 +366,7 @@ __device__ __forceinline__ void sweep(const LatticeArgs& a, const Item it, const
             // followed every edge of the control-flow graph instead of one path, pointed at it; tools/wd_soak.py had
             // shown the symptoms (profiles/r05_wd_soak.txt: the blocks of 16 diagonals, whose twelve reloads per dry block
             // happened to share registers with the offsets).
-            ws::wait_lds();
+            ws::wait_lds_keep<K, HAS_LEFT>(cur2, seed4);   // (the refilled registers are operands of the wait: lattice_step.h)
             if (!dry) {
                 __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
