@@ -3,19 +3,30 @@
  * (libwarp_rnnt_amd.so).  Plain pointers and sizes only; every pointer is a
  * DEVICE pointer unless stated otherwise; every call only ENQUEUES work on
  * `stream` (no allocation, no host synchronisation), so the library is
- * re-entrant across streams and threads.  State the library keeps, all of it
- * harmless to share: the lattice route and the log-domain kernel override
- * (rnnt_amd_set_lattice, rnnt_amd_set_logdomain_kernel: one atomic int each,
- * read once per call), a launch counter per process and one per device (they
- * only make the hand-over tags of the column-block lattice kernels unique
- * per launch and per graph replay), kernel-selection knobs for A/B runs, each
- * read once from the environment and none of them changing a result beyond
- * fp32 rounding of the log-softmax (RNNT_LSM_*, RNNT_LG_*, RNNT_LSMBWD_*,
- * RNNT_GATHER_*, RNNT_COMPACT_*, RNNT_DENSE_ONE_LAUNCH_CELLS, RNNT_WD_LONE_FROM_T:
- * the table in DESIGN.md section 10), a per-thread status
- * for the void-returning compact entry points (rnnt_amd_compact_last_status)
- * and a once-per-process kernel attribute.  Nothing depends on what an earlier
- * call left in a workspace: scratch contents are unspecified on entry and exit.
+ * re-entrant across streams and threads.  What the library keeps between calls:
+ * a launch counter per process and one per device (they only make the hand-over
+ * tags of the column-block lattice kernel unique per launch and per graph
+ * replay), a sticky per-device word that the gradient kernel sets when the
+ * forward/backward guard fires (rnnt_amd_mismatch_flag: diagnostics only), a
+ * per-thread status for the void-returning compact entry points
+ * (rnnt_amd_compact_last_status), a once-per-process kernel attribute, and a
+ * handful of kernel-selection knobs for A/B runs that are read once from the
+ * environment -- none of them changes a bit of a result
+ * except the log-softmax knobs, and those only its fp32 rounding.  One arithmetic
+ * (the reference's) serves every call; nothing a caller can set changes it.
+ * The only setter, rnnt_amd_debug_set_lattice_kernel, pins which of several
+ * bit-identical kernels runs and exists for tests and A/B timing.  Nothing
+ * depends on what an earlier call left in a workspace: scratch contents are
+ * unspecified on entry and exit.
+ *
+ * Sizes every entry point takes (anything else: RNNT_STATUS_INVALID_ARGUMENT
+ * before any launch -- the void compact entries report it their way):
+ *     1 <= T, 1 <= U, 0 <= N <= 65535        (N: gridDim.y of the gradient kernel)
+ *     T * U   <  2^29                         (one utterance's plane of pairs < 4 GiB: 32-bit buffer offsets)
+ *     N * T * U < 2^32                        (flat cell index)
+ *     dense (N,T,U,V) entries also: U * V < 2^31
+ * The reference's own limit is lower: its `int` index arithmetic overflows at
+ * N*T*U*V >= 2^31 elements (core.cu:14-24).
  *
  * Part 1 mirrors the reference's own C interface (1ytic/warp-rnnt core.h: all
  * five entry points, padded and compact) so that the reference's bindings can
@@ -65,6 +76,8 @@ typedef enum {
  *     the first N words of counts hold the alpha-side log-likelihoods as fp32 bits).  counts need
  *     not be zeroed.
  *   costs (N,): out.
+ * Sizes: see the head of this file (N <= 65535, T*U < 2^29, N*T*U < 2^32; here also U*V < 2^31 for
+ *   the fast path -- beyond it the call still runs, on the single-role kernel): status 5 otherwise.
  * Lengths: the reference does not check 1 <= xn[n] <= T, 0 <= yn[n] <= U-1 (binding.cpp:47-51)
  *   and reads out of range when they are violated.  Every entry point of this library checks
  *   them on the device (no host sync): an offending utterance gets costs[n] = NaN and no
@@ -79,6 +92,9 @@ rnntStatus_t run_warp_rnnt(rnntStream_t stream, unsigned int *counts, float *alp
  * Replaces run_warp_rnnt_gather (core.h:35-39, core_gather.cu:359-388): gathered layout,
  *   log_probs and grads (N,T,U,2) with channel 0 = blank, channel 1 = label.
  *   grads is fully written (zeros included); pre-zeroing is allowed but not needed.
+ *   Sizes: N <= 65535, T*U < 2^29, N*T*U < 2^32 (status 5 otherwise).  counts / alphas / betas: scratch
+ *   as above (from 2^20 cells on alphas / betas are also used to park the gradient channels: they hold no
+ *   defined values on return, as in the reference, whose binding never reads them back).
  */
 rnntStatus_t run_warp_rnnt_gather(rnntStream_t stream, unsigned int *counts, float *alphas,
                                   float *betas, const float *log_probs, float *grads, float *costs,
@@ -96,7 +112,12 @@ rnntStatus_t run_warp_rnnt_gather(rnntStream_t stream, unsigned int *counts, flo
  * memory), and a per-host-thread status returned (and cleared) by rnnt_amd_compact_last_status() -- poll it after
  * run_warp_rnnt_compact if you can.  Lengths with xn < 1 give cost NaN and
  * touch nothing; required_grad == 0 computes betas and costs only and never writes alphas / grads (the reference
- * aliases both to betas then, binding.cpp:192-195).  Gradients honour the alpha/beta consistency guard of the
+ * aliases both to betas then, binding.cpp:192-195).  `alphas` / `betas` are SCRATCH for run_warp_rnnt_compact, not
+ * outputs: with required_grad and a launch bound of N*T*U >= 2^20 cells the call parks the two gradient channels in
+ * them on its way to the row-major result, below that they hold the lattices in diagonal-major order -- what they hold
+ * on return depends on the batch size and is unspecified (binding.cpp:186-199 allocates them with torch::empty and
+ * drops them).  A caller that wants alphas / betas uses the padded entries with a batch below 2^20 cells or reads them
+ * from the native workspace (rnnt_amd_workspace_size: alphas at offset 0, betas behind, diagonal-major).  Gradients honour the alpha/beta consistency guard of the
  * padded kernels (core_gather.cu:341-354), which the reference's compact kernels lack.
  * The native compact interface further down (rnnt_amd_loss_compact ...) does the same work on the caller's
  * stream with status codes and is what the bundled host code uses.
@@ -145,6 +166,25 @@ size_t rnnt_amd_workspace_size(int N, int T, int U);
 size_t rnnt_amd_workspace_mismatch_offset(int N, int T, int U);
 
 /*
+ * The same guard, process-wide and without a read-back of anybody's workspace -- the counterpart of the reference's
+ * device-side printf ("WARNING: sample %d [%d, %d] has a forward/backward mismatch %f / %f", core_gather.cu:345-349),
+ * which a caller of this library would otherwise lose.  Returns a HOST pointer to eight words of pinned, device-mapped
+ * memory belonging to `device` (NULL: device index out of range, or the allocation failed); from this call on, every
+ * entry point of the library whose gradient kernel zeroes an utterance's gradients on `device` -- the guard fired, or
+ * the lengths were out of range -- also writes there, from the kernel, with no host synchronisation and at no cost when
+ * nothing fires:
+ *   [0] != 0  something fired since the reader last stored 0 here (the reader clears it; written last)
+ *   [1] kind: 1 forward/backward mismatch, 2 lengths out of range     [2] utterance index n in its batch
+ *   [3] xn[n]   [4] yn[n]   [5] alpha-side log-likelihood (fp32 bits)   [6] beta[0,0] (fp32 bits)   [7] unused
+ * The words are sticky (nothing but the reader resets them) and describe the LAST firing.  Read them whenever convenient:
+ * after a synchronisation they are exact; without one they lag by the kernels still in flight.  The first call
+ * allocates the table (one hipHostMalloc per process, never freed): do not make it inside a stream capture.  Until the
+ * first call the kernels write nothing.  The bundled Python host calls it once per device and turns [0] into one
+ * RuntimeWarning per firing (warp_rnnt_amd.last_mismatch()).
+ */
+volatile unsigned *rnnt_amd_mismatch_flag(int device);
+
+/*
  * The loss: costs (N,) and gradients in one call.
  *   workspace: >= rnnt_amd_workspace_size(N,T,U) bytes, 256-byte aligned, contents unspecified.
  *   labels may be NULL for RNNT_IN_LOG_PROBS_GATHERED or when U == 1.
@@ -155,15 +195,6 @@ rnntStatus_t rnnt_amd_loss(rnntStream_t stream, void *workspace, int input_kind,
                            const int *labels, const int *xn, const int *yn, float *costs, float *grads,
                            int grads_kind, int N, int T, int U, int V, int blank,
                            float fastemit_lambda);
-
-/* The same call with the arithmetic of the alpha / beta sweeps chosen for THIS call: `lattice` = 0 auto, 1 logdomain,
- * 2 pd (the values of rnnt_amd_set_lattice below), or RNNT_LATTICE_DEFAULT = whatever rnnt_amd_set_lattice last set --
- * which is what rnnt_amd_loss passes.  No state is read or written: threads that want different routes use this. */
-#define RNNT_LATTICE_DEFAULT (-1)
-rnntStatus_t rnnt_amd_loss_ex(rnntStream_t stream, void *workspace, int input_kind, const float *input,
-                              const int *labels, const int *xn, const int *yn, float *costs, float *grads,
-                              int grads_kind, int N, int T, int U, int V, int blank,
-                              float fastemit_lambda, int lattice);
 
 /*
  * Backward of the gather prologue (warp_rnnt/__init__.py:21-24,126): expands
@@ -187,8 +218,8 @@ rnntStatus_t rnnt_amd_expand_grads(rnntStream_t stream, const float *grads_diago
  *   loc (STU,) int64 vocabulary index of the label channel per row (NULL = not wanted).
  */
 /* Scratch for rnnt_amd_loss_compact with the same N, STU, Tmax, Umax (0 = these sizes are not supported).
- * (Since version 102 the launch bounds are arguments: the probability-domain lattice kernel keeps its
- * hand-over rings here too, and their size depends on Tmax and Umax.) */
+ * (The launch bounds are arguments because the hand-over rings of k_lattice_wd live here too, and their
+ * size depends on Tmax and Umax.) */
 size_t rnnt_amd_workspace_size_compact(int N, int64_t STU, int Tmax, int Umax);
 /* One launch for what binding.cpp:139-170 does with a chain of tensor ops: cell_offsets (N+1,) int64 and
  * label_offsets (N+1,) int32 exclusive prefix sums of xn*(yn+1) and yn, and
@@ -201,13 +232,6 @@ rnntStatus_t rnnt_amd_loss_compact(rnntStream_t stream, void *workspace, const f
                                    const int *label_offsets, float *costs, float *grads2, int64_t *loc,
                                    int N, int64_t STU, int Tmax, int Umax, int V, int blank,
                                    float fastemit_lambda);
-
-/* ... with the lattice route of this call (see rnnt_amd_loss_ex) */
-rnntStatus_t rnnt_amd_loss_compact_ex(rnntStream_t stream, void *workspace, const float *xs, const int *ys,
-                                      const int *xn, const int *yn, const int64_t *cell_offsets,
-                                      const int *label_offsets, float *costs, float *grads2, int64_t *loc,
-                                      int N, int64_t STU, int Tmax, int Umax, int V, int blank,
-                                      float fastemit_lambda, int lattice);
 
 /* The same in ONE call with launch bounds the caller supplies (Tmax >= every xn, Umax >= every yn + 1; n_labels = the
  * number of elements of ys): offsets, maxima and the shape checks stay on the device, nothing is read back, so the call
@@ -262,52 +286,32 @@ rnntStatus_t rnnt_amd_debug_lattice_only(rnntStream_t stream, void *workspace, c
 rnntStatus_t rnnt_amd_debug_gather_only(rnntStream_t stream, void *workspace, const float *log_probs,
                                         const int *labels, int N, int T, int U, int V, int blank);
 
-/* Diagnostics (tests/pd_vs_oracle.py): byte offset, inside the workspace, of the (2N,) int32 flags the
- * probability-domain lattice kernel leaves for the log-domain kernel launched behind it: flags[2n+dir] != 0 means
- * sweep `dir` (0 alpha, 1 beta) of utterance n was redone in the log domain (bit 0: an input outside the range
- * the probability domain carries; bit 1: a hand-over between column blocks timed out). */
+/* Diagnostics (tools/wd_soak.py, tests/test_gpu_wd.py): byte offset, inside the workspace, of the (2N,) int32 flags
+ * k_lattice_wd leaves for the single-workgroup kernel launched behind it: flags[2n+dir] & 2 means a hand-over
+ * between column blocks of sweep `dir` (0 alpha, 1 beta) of utterance n timed out and the sweep was redone. */
 size_t rnnt_amd_debug_redo_offset(int N, int T, int U);
 
 /*
- * Which arithmetic sweeps the lattice of the workspace-based calls (rnnt_amd_loss, rnnt_amd_loss_compact):
- *   0 auto       (default) the reference's arithmetic: fp32 log-sum-exp per cell (core_gather.cu:22-35,106-126).
- *                Results are the same bits whatever the batch they were computed in: the kernel is chosen by shape
- *                (one workgroup per sweep / one per 64-column block), both run the same step function;
- *   1 logdomain  the same, said explicitly (kept from the rounds in which `auto` took the probability domain on long
- *                lattices of small batches);
- *   2 pd         probability domain (fp64 mantissa + per-column exponent) wherever it is supported
- *                (padded or native compact layout, U <= 512), log domain elsewhere.  Opt-in: closer to exact arithmetic
- *                on long lattices -- the log domain accumulates ~ulp(|alpha|) per step (1e-2 on the gradients at T=1500,
- *                U=300, the reference's included), the probability domain does not (7e-4) -- at the reference's speed
- *                or better only while 2N*ceil(U/64) <= the number of compute units.
- * Process-wide, read once per call, may be changed at any time: the DEFAULT of every call that does not name a route
- * itself.  Callers on several threads that want different routes pass theirs per call -- rnnt_amd_loss_ex /
- * rnnt_amd_loss_compact_ex, `lattice=` in warp_rnnt_amd.ops -- and leave this setting alone.
- * The initial value comes from the environment variable RNNT_LATTICE (logdomain | pd).  The
- * reference-named entry points of Part 1 always run the log domain.  Returns the previous setting, or -1 for an
- * unknown value.
- */
-int rnnt_amd_set_lattice(int route);
-int rnnt_amd_get_lattice(void);
-
-/*
- * Which KERNEL serves the log-domain arithmetic where two can (speed only -- they share the step function and produce
- * the same bits, tests/test_gpu_wd.py):
+ * DEBUG / A-B ONLY.  Which KERNEL runs the sweeps where several can (speed only: they put the same instructions on the
+ * chain and produce the same bits, tests/test_gpu_wd.py; the arithmetic is always the reference's fp32 log-sum-exp per
+ * cell, core_gather.cu:22-35,106-126 -- until version 105 a second arithmetic could be selected with
+ * rnnt_amd_set_lattice; it is gone, and so are rnnt_amd_loss_ex / rnnt_amd_loss_compact_ex that chose it per call):
  *   0 by shape   (default)
  *   1 ws         all column blocks of a sweep in one workgroup, one compute + one I/O wave each (csrc/lattice_ws.hip; U <= 512)
  *   2 wd         one workgroup per 64-column block, boundary columns through L2 rings (csrc/lattice_wd.hip; any U)
  *   3 wl         the single-workgroup form of wd (k_lattice_wl: three waves per column block, boundary columns through
  *                LDS), wherever the workgroup's LDS holds the lattice's column blocks
- * Process-wide, read once per call; initial value from the environment variable RNNT_LOGDOMAIN_KERNEL (ws | wd | wl).
- * Returns the previous setting, or -1 for an unknown value.  A tuning and test knob, not part of the numerics contract.
+ * One process-wide atomic, read once per call; initial value from the environment variable
+ * RNNT_DEBUG_LATTICE_KERNEL (ws | wd | wl).  Returns the previous setting, or -1 for an unknown value.  Nothing in the
+ * product sets it; not part of any contract.
  */
-int rnnt_amd_set_logdomain_kernel(int kernel);
-int rnnt_amd_get_logdomain_kernel(void);
+int rnnt_amd_debug_set_lattice_kernel(int kernel);
+int rnnt_amd_debug_get_lattice_kernel(void);
 
-/* Diagnostics (bench.py's `lattice_route`, tests): the lattice kernel the calling thread's last loss call launched --
- * 1 lattice_ws (log domain, one workgroup per sweep), 2 lattice_wd (log domain, one per column block), 3 lattice_pd
- * (probability domain), 4 the single-role kernel of lattice.hip (reference layouts, stripes), 5 lattice_wl (log domain,
- * one workgroup per sweep, the wave roles of lattice_wd); 0 before the first call. */
+/* Diagnostics (bench.py's `lattice_kernel`, tests): the lattice kernel the calling thread's last loss call launched --
+ * 1 lattice_ws (one workgroup per sweep), 2 lattice_wd (one per column block), 4 the single-role kernel of lattice.hip
+ * (reference layouts, stripes), 5 lattice_wl (one workgroup per sweep, the wave roles of lattice_wd); 0 before the
+ * first call (3 was the retired probability-domain kernel). */
 int rnnt_amd_debug_last_lattice_kernel(void);
 
 /* Library version, for the host-side loader. */

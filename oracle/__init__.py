@@ -118,3 +118,42 @@ def num_threads():
 
 def set_threads(n):
     lib().oracle_set_threads(int(n))
+
+
+def grad_error_report(hip_pairs, ref, xn, yn, threshold=1e-4):
+    """How far gathered gradient pairs (N,T,U,2) of the HIP path are from the oracle's (``ref`` = rnnt_loss_f32's dict on
+    the gathered layout), in the terms of the fp32 argument that explains the distance on long lattices.
+
+    A gradient is ``-exp((alpha + beta) + lp - beta00)``: its argument is a difference of numbers of magnitude
+    |log-likelihood| (6e3 at T=1500, U=300, V=50), so ONE ulp of the plane values -- 4.9e-4 there -- moves the argument, and
+    with it a gradient of magnitude ~1, by that much.  Two fp32 implementations of the same operation order that differ
+    in the last bit of a transcendental somewhere along 1800 dependent steps therefore differ by a few ulp OF THE PLANE
+    VALUE on the handful of cells that carry the path's mass, and by nothing visible elsewhere.  Returned:
+      max_abs, p999                       over all live slots
+      cells_above, frac_above             live slots with |delta| > threshold (1e-4: BASELINE.json's fp32 bar)
+      max_ulp_of_plane                    max over live slots of |delta| / ulp32(max(|alpha|, |beta|, |alpha + beta|))
+      min_plane_magnitude_above           the smallest such plane magnitude among the slots above the threshold
+                                          (None if there are none): the claim is that it is >= 2^11
+    """
+    g = np.asarray(hip_pairs, dtype=np.float64)
+    r = np.asarray(ref["grads"], dtype=np.float64)
+    N, T, U, _ = g.shape
+    t = np.arange(T)[None, :, None]
+    u = np.arange(U)[None, None, :]
+    xn = np.asarray(xn)
+    yn = np.asarray(yn)
+    cell = (t < xn[:, None, None]) & (u <= yn[:, None, None])
+    live = np.stack([cell, cell & (u < yn[:, None, None])], axis=-1)
+    a = np.abs(ref["alphas"].astype(np.float64))
+    b = np.abs(ref["betas"].astype(np.float64))
+    mag = np.maximum(np.maximum(a, b), np.abs(ref["alphas"].astype(np.float64) + ref["betas"].astype(np.float64)))
+    ulp = np.spacing(np.maximum(mag, 1.0).astype(np.float32)).astype(np.float64)[..., None]
+    d = np.abs(g - r)
+    dl = d[live]
+    above = live & (d > threshold)
+    n_above = int(above.sum())
+    mags_above = np.broadcast_to(mag[..., None], d.shape)[above]
+    return {"max_abs": float(dl.max()), "p999": float(np.quantile(dl, 0.999)),
+            "cells_above": n_above, "frac_above": n_above / max(int(live.sum()), 1), "threshold": threshold,
+            "max_ulp_of_plane": float((d / ulp)[live].max()),
+            "min_plane_magnitude_above": float(mags_above.min()) if n_above else None}

@@ -259,35 +259,35 @@ def test_reference_named_compact_entry_points_staged(N, Tm, Um, V, kernel):
     lastcol = np.concatenate([np.tile(np.arange(yn[n] + 1) == yn[n], xn[n]) for n in range(N)])
     g2[lastcol, 1] = 0
     np.testing.assert_allclose(grads.cpu().numpy(), g2, atol=5e-4)
-    with warp_rnnt_amd.lattice_route("logdomain"):
-        c_nat, g_nat, loc_nat = core.rnnt_loss_compact(T(xs), T(ys), T(xn), T(yn), blank=0, fastemit_lambda=lam)
+    c_nat, g_nat, loc_nat = core.rnnt_loss_compact(T(xs), T(ys), T(xn), T(yn), blank=0, fastemit_lambda=lam)
     assert torch.equal(c_nat, costs) and torch.equal(g_nat, grads) and torch.equal(loc_nat, loc)
     # costs-only mode (alphas and grads alias betas: the direct form)
     c2, _, _, _ = _ref_compact_abi(xs, ys, xn, yn, 0, lam, required_grad=False)
     np.testing.assert_allclose(c2.cpu().numpy(), ref["costs"], rtol=1e-5)
 
 
-@pytest.mark.parametrize("route", ["logdomain", "pd", "auto"])
+@pytest.mark.parametrize("kernel", ["auto", "ws", "wd", "wl"])
 @pytest.mark.parametrize("N,Tm,Um,V,lam", [
     (3, 40, 12, 9, 0.0),          # one column block
     (3, 70, 150, 5, 0.02),        # three column blocks, ragged ends in different blocks
-    (2, 700, 200, 6, 0.0),        # long lattice: the distributed log-domain kernel on "auto", the probability domain on "pd"
+    (2, 700, 200, 6, 0.0),        # long lattice: the distributed kernel by itself (rings sized by the launch bounds Tmax / Umax)
     (5, 9, 1, 4, 0.0),            # no labels at all
 ])
-def test_compact_on_both_lattice_routes(route, N, Tm, Um, V, lam):
-    """The compact layout runs on either lattice arithmetic (round 3: the probability-domain kernel's COMPACT
-    instantiation, its hand-over rings sized by the launch bounds Tmax / Umax): gathered (STU,2) gradients and costs
-    against the fp32 oracle on every route, and identical costs-only results."""
-    import warp_rnnt_amd
-    from warp_rnnt_amd import ops
+def test_compact_on_every_lattice_kernel(kernel, N, Tm, Um, V, lam):
+    """The compact layout on every lattice kernel (each has a COMPACT instantiation; the hand-over rings of k_lattice_wd
+    are sized by the launch bounds Tmax / Umax): gathered (STU,2) gradients and costs against the fp32 oracle, the same
+    bits whichever kernel ran, and identical costs-only results."""
+    from warp_rnnt_amd import debug, ops
     logits, labels, xn, yn = make_case(500 + Tm + Um, N, Tm, Um, V, ragged=True)
     lp = np_log_softmax32(logits)
     ref = oracle.rnnt_loss_f32(lp, labels, xn, yn, fastemit_lambda=lam, scan_mode=1)
     xs, ys = pack(lp, labels, xn, yn)
-    with warp_rnnt_amd.lattice_route(route):
+    c_auto, g_auto, _ = ops.loss_compact(T(xs), T(ys), T(xn), T(yn), 0, lam)
+    with debug.lattice_kernel(kernel):
         costs, grads2, loc = ops.loss_compact(T(xs), T(ys), T(xn), T(yn), 0, lam)
         c_only, g_none, _ = ops.loss_compact(T(xs), T(ys), T(xn), T(yn), 0, lam, required_grad=False)
     torch.cuda.synchronize()
+    assert torch.equal(costs, c_auto) and torch.equal(grads2, g_auto)
     np.testing.assert_allclose(costs.cpu().numpy(), ref["costs"], rtol=1e-5)
     np.testing.assert_array_equal(c_only.cpu().numpy(), costs.cpu().numpy())
     assert g_none is None

@@ -540,8 +540,63 @@ def test_mismatch_policy_env(monkeypatch):
     monkeypatch.setenv("WARP_RNNT_AMD_CHECK_MISMATCH", "raise")
     with pytest.raises(RuntimeError, match="forward/backward mismatch"):
         core.rnnt_loss(t32(lp2), ys, t32(xn), t32(yn), blank=-1)
-    monkeypatch.delenv("WARP_RNNT_AMD_CHECK_MISMATCH")
-    core.rnnt_loss(t32(lp2), ys, t32(xn), t32(yn), blank=-1)       # default: silent, flags stay on the device
+    monkeypatch.setenv("WARP_RNNT_AMD_CHECK_MISMATCH", "off")
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        core.rnnt_loss(t32(lp2), ys, t32(xn), t32(yn), blank=-1)   # off: nothing is looked at, nothing is said
+        torch.cuda.synchronize()
+        core.rnnt_loss(t32(lp2), ys, t32(xn), t32(yn), blank=-1)
+
+
+def test_mismatch_warning_is_on_by_default_and_needs_no_synchronisation(monkeypatch):
+    """The reference prints "WARNING: sample %d [%d, %d] has a forward/backward mismatch %f / %f" from the device whenever
+    its guard fires (core_gather.cu:345-349).  Here, by default: the gradient kernel writes the same facts to the device's
+    sticky words in pinned host memory (rnnt_amd_mismatch_flag), and the host looks at them around the next call and in
+    every backward -- a memory read, no synchronisation -- and warns once per firing.  Through the drop-in wrapper (both
+    bindings), dense and gather=True, and the accessor."""
+    import warnings
+    import warp_rnnt
+    import warp_rnnt_amd
+    from warp_rnnt_amd import _mismatch
+    monkeypatch.delenv("WARP_RNNT_AMD_CHECK_MISMATCH", raising=False)
+    lp2, xn, yn = _guard_case()
+    V, labels = 5, np.array([[1, 2, 3]] * 3, dtype=np.int32)
+    dense = np.full((3, 1, 4, V), -9.0, dtype=np.float32)
+    dense[..., 0] = lp2[..., 0]
+    for u in range(3):
+        dense[:, 0, u, labels[0, u]] = lp2[:, 0, u, 1]
+    torch.cuda.synchronize()
+    warp_rnnt_amd.last_mismatch()                                   # drain whatever earlier tests left behind
+    seen0 = (warp_rnnt_amd.last_mismatch() or {"seen": 0})["seen"]
+    for gather in (False, True):
+        x = t32(dense).requires_grad_(True)
+        with warnings.catch_warnings():
+            warnings.simplefilter("error")                          # the forward call itself never waits, never warns
+            costs = warp_rnnt.rnnt_loss(x, t32(labels), t32(xn), t32(yn), gather=gather)
+        torch.cuda.synchronize()                                    # (the test's own: so that the kernel HAS fired)
+        with pytest.warns(RuntimeWarning, match=r"sample 1 \[1, 3\] has a forward/backward mismatch -2\.0+ / 0\.0+"):
+            costs.sum().backward()                                  # the look in backward finds it
+        assert not x.grad[1].any().item() and costs[1].item() == 1.0
+        info = warp_rnnt_amd.last_mismatch()
+        assert info["kind"] == "mismatch" and info["utterance"] == 1 and info["frames"] == 1 and info["labels"] == 3
+        assert info["loglik_alpha"] == -2.0 and info["loglik_beta"] == 0.0 and info["device"] == 0
+    assert warp_rnnt_amd.last_mismatch()["seen"] == seen0 + 2
+    # a clean batch says nothing, before or after
+    lpc = t32(np.full((2, 3, 4, 2), -1.0, np.float32))
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        core_costs = warp_rnnt._C.rnnt_loss(lpc, torch.zeros((2, 3), dtype=torch.int32, device=dev()),
+                                            t32(np.full((2,), 3, np.int32)), t32(np.full((2,), 3, np.int32)), blank=-1)
+        torch.cuda.synchronize()
+        _mismatch.poll(torch.device("cuda:0"))
+    assert torch.isfinite(core_costs[0]).all()
+    # invalid lengths go the same way (the reference reads out of bounds there)
+    bad_xn = np.array([1, 7, 1], dtype=np.int32)                     # 7 > T = 1
+    warp_rnnt._C.rnnt_loss(t32(lp2), torch.zeros((3, 3), dtype=torch.int32, device=dev()), t32(bad_xn), t32(yn), blank=-1)
+    torch.cuda.synchronize()
+    with pytest.warns(RuntimeWarning, match="sample 1 has lengths out of range"):
+        assert warp_rnnt_amd.last_mismatch()["kind"] == "invalid lengths"
 
 
 # ----------------------------------------------------------------------------
@@ -627,7 +682,7 @@ def _same_pattern(got_c, got_g, ref, atol, what):
 @pytest.mark.parametrize("N,T,U,V", [(5, 9, 6, 5), (5, 70, 40, 6), (5, 260, 150, 5), (6, 80, 330, 4)])
 def test_masked_log_probs_nan_pattern_equals_the_oracles(N, T, U, V):
     import warp_rnnt
-    import warp_rnnt_amd
+    from warp_rnnt_amd import debug
     np.seterr(all="ignore")
     lp, labels, xn, yn = _masked_case(N, T, U, V, 4242 + T)
     ref = oracle.rnnt_loss_f32(lp, labels, xn, yn, blank=0, scan_mode=1)
@@ -635,20 +690,13 @@ def test_masked_log_probs_nan_pattern_equals_the_oracles(N, T, U, V):
     lp2 = oracle.gather_f32(lp, labels, 0)
     ref2 = oracle.rnnt_loss_f32(lp2, labels, xn, yn, blank=-1, scan_mode=1)
     atol = 1e-4 if T + U <= 250 else 5e-4
-    # native op, dense and gathered layouts, under every kernel of the log-domain route and under the pd route (whose
-    # input check hands masked utterances to the log-domain kernel)
+    # native op, dense and gathered layouts, under every lattice kernel
     for kern in ("auto", "ws", "wd", "wl"):
-        old = warp_rnnt_amd.set_logdomain_kernel(kern)
-        try:
+        with debug.lattice_kernel(kern):
             c, g = run_native(lp, labels, xn, yn, blank=0)
             _same_pattern(c, g, ref, atol, f"dense, kernel {kern}")
             c2, g2 = run_native(lp2, labels, xn, yn, blank=-1)
             _same_pattern(c2, g2, ref2, atol, f"gathered, kernel {kern}")
-        finally:
-            warp_rnnt_amd.set_logdomain_kernel(old)
-    with warp_rnnt_amd.lattice_route("pd"):
-        c2, g2 = run_native(lp2, labels, xn, yn, blank=-1)
-    _same_pattern(c2, g2, ref2, atol, "gathered, pd route")
     # reference C ABI, both layouts
     ca, ga = _call_ref_abi(lp, labels, xn, yn, 0, 0.0)
     _same_pattern(ca, ga, ref, atol, "run_warp_rnnt")
@@ -690,33 +738,43 @@ def test_the_reference_named_entry_points_give_one_utterance_the_same_bits_in_an
         np.testing.assert_array_equal(g_big[-2:], g_small)
 
 
-def test_lattice_route_per_call():
-    """ops.loss(..., lattice=) / rnnt_amd_loss_ex: the route of ONE call, whatever the process-wide setting says, and
-    without touching it."""
+def test_one_arithmetic_and_a_debug_only_kernel_pin():
+    """Round 6: the library has ONE arithmetic (the probability-domain route and the per-call / process-wide route
+    settings are gone: nothing a caller can set changes a bit of the result).  What is left is a debug pin of the KERNEL,
+    and every kernel gives the same bits; two threads with different pins cannot disagree."""
+    import threading
     import warp_rnnt_amd
-    from warp_rnnt_amd import ops
-    N, T, U, V = 3, 700, 70, 6                                      # long enough for the probability domain to differ
+    from warp_rnnt_amd import debug, ops
+    N, T, U, V = 3, 700, 70, 6
     logits, labels, xn, yn = make_case(5, N, T, U, V, ragged=True)
     lp2 = t32(oracle.gather_f32(np_log_softmax32(logits), labels, 0))
     txn, tyn = t32(xn), t32(yn)
-    run = lambda **kw: ops.loss(lp2, None, txn, tyn, ops.IN_LOG_PROBS_GATHERED, ops.GRADS_GATHERED, **kw)   # noqa: E731
-    assert warp_rnnt_amd.get_lattice() == "auto"
-    c_def, g_def = run()
-    c_log, g_log = run(lattice="logdomain")
-    c_pd, g_pd = run(lattice="pd")
-    assert warp_rnnt_amd.last_lattice_kernel() == "lattice_pd" and warp_rnnt_amd.get_lattice() == "auto"
-    assert torch.equal(c_def, c_log) and torch.equal(g_def, g_log)
-    assert not torch.equal(g_pd, g_log)                             # another arithmetic ...
-    np.testing.assert_allclose(g_pd.cpu().numpy(), g_log.cpu().numpy(), atol=2e-3)   # ... of the same quantity
-    with warp_rnnt_amd.lattice_route("pd"):                         # the process-wide default is only a default
-        c, g = run(lattice="logdomain")
-        assert torch.equal(c, c_log) and torch.equal(g, g_log)
-        c, g = run()
-        assert torch.equal(g, g_pd)
-    with pytest.raises(ValueError, match="unknown lattice route"):
-        run(lattice="exact")
+    run = lambda: ops.loss(lp2, None, txn, tyn, ops.IN_LOG_PROBS_GATHERED, ops.GRADS_GATHERED)   # noqa: E731
+    for gone in ("set_lattice", "get_lattice", "lattice_route", "set_logdomain_kernel"):
+        assert not hasattr(warp_rnnt_amd, gone), gone
     L = warp_rnnt_amd.load()
-    assert L.rnnt_amd_loss_ex(None, None, 0, None, None, None, None, None, None, 0, 1, 1, 1, 1, 0, 0.0, 7) == 5
+    for gone in ("rnnt_amd_set_lattice", "rnnt_amd_loss_ex", "rnnt_amd_loss_compact_ex", "rnnt_amd_set_logdomain_kernel"):
+        assert not hasattr(L, gone), gone
+    with pytest.raises(TypeError):
+        ops.loss(lp2, None, txn, tyn, ops.IN_LOG_PROBS_GATHERED, ops.GRADS_GATHERED, lattice="pd")
+    assert debug.get_lattice_kernel() == "auto"
+    c_def, g_def = run()
+    results = {}
+
+    def worker(kern):
+        for _ in range(20):
+            with debug.lattice_kernel(kern):       # (process-wide: the threads race on the pin -- and it must not matter)
+                results[kern] = run()
+    threads = [threading.Thread(target=worker, args=(k,)) for k in ("ws", "wl")]
+    [t.start() for t in threads]
+    [t.join() for t in threads]
+    torch.cuda.synchronize()
+    for kern, (c, g) in results.items():
+        assert torch.equal(c, c_def) and torch.equal(g, g_def), kern
+    debug.set_lattice_kernel("auto")
+    with pytest.raises(ValueError, match="unknown lattice kernel"):
+        debug.set_lattice_kernel("exact")
+    assert L.rnnt_amd_debug_set_lattice_kernel(9) == -1 and debug.get_lattice_kernel() == "auto"
 
 
 @pytest.mark.parametrize("N,T,U", [(3, 100, 9), (3, 100, 33), (2, 200, 65), (2, 300, 129), (3, 90, 41)])
@@ -725,7 +783,7 @@ def test_last_column_starting_on_a_block_boundary(N, T, U):
     diagonal of a block.  It must be computed by a block variant that knows the rim rule (and, in the column-block
     kernels, before the steady-state blocks take over: what a lane holds before its first cell is unspecified there).
     With the label arc into that cell masked: alpha[0, U-1] = -inf exactly, a finite cost, no NaN anywhere."""
-    import warp_rnnt_amd
+    from warp_rnnt_amd import debug
     np.seterr(all="ignore")
     logits, labels, xn, yn = make_case(900 + U, N, T, U, 5)
     lp = np_log_softmax32(logits)
@@ -735,11 +793,8 @@ def test_last_column_starting_on_a_block_boundary(N, T, U):
     ref = oracle.rnnt_loss_f32(lp2, labels, xn, yn, blank=-1, scan_mode=1)
     assert np.isfinite(ref["costs"]).all() and np.isneginf(ref["alphas"][0, 0, U - 1])
     for kern in ("auto", "ws", "wd", "wl"):
-        old = warp_rnnt_amd.set_logdomain_kernel(kern)
-        try:
+        with debug.lattice_kernel(kern):
             c, g = run_native(lp2, labels, xn, yn, blank=-1)
-        finally:
-            warp_rnnt_amd.set_logdomain_kernel(old)
         _same_pattern(c, g, ref, 1e-4 if T + U <= 250 else 5e-4, f"kernel {kern}")
     ca, ga = _call_ref_abi(lp2, labels, xn, yn, -1, 0.0)
     _same_pattern(ca, ga, ref, 1e-4 if T + U <= 250 else 5e-4, "run_warp_rnnt_gather")

@@ -6,7 +6,7 @@ operations in the same order: these tests are what holds the two implementations
 
 Both kernels call the same step function (csrc/lattice_step.h), so they must agree BIT FOR BIT on costs and gradients
 whatever the shape, the batch size, the layout and the timing of the hand-overs -- that is what makes the kernel choice a
-pure speed knob inside the `logdomain` route (the reference's arithmetic, core_gather.cu:22-35,106-126)."""
+pure speed knob (one arithmetic: the reference's, core_gather.cu:22-35,106-126)."""
 import os
 import subprocess
 import sys
@@ -16,9 +16,8 @@ import pytest
 import torch
 
 import oracle
-import warp_rnnt_amd
 from helpers import make_case, np_log_softmax32
-from warp_rnnt_amd import ops
+from warp_rnnt_amd import debug, ops
 
 pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -31,15 +30,10 @@ def _pairs(logits, labels, blank=0):
 
 
 def _run(lp2, xn, yn, kernel, lam=0.0):
-    old_r = warp_rnnt_amd.set_lattice("logdomain")
-    old_k = warp_rnnt_amd.set_logdomain_kernel(kernel)
-    try:
+    with debug.lattice_kernel(kernel):
         costs, grads = ops.loss(lp2, None, xn, yn, ops.IN_LOG_PROBS_GATHERED, ops.GRADS_GATHERED, fastemit_lambda=lam)
         torch.cuda.synchronize()
         return costs, grads
-    finally:
-        warp_rnnt_amd.set_lattice(old_r)
-        warp_rnnt_amd.set_logdomain_kernel(old_k)
 
 
 # (N, T, U, ragged): one, two and many column blocks; widths one short of / one beyond a block; lattices shorter than a
@@ -70,7 +64,7 @@ def test_same_bits_as_the_single_workgroup_kernel(N, T, U, ragged):
     # take every lattice its LDS holds: U <= 320, 148 KiB -- beyond that the call falls through to lattice_ws.hip)
     c_wl, g_wl = _run(lp2, txn, tyn, "wl", lam=0.01)
     if 64 < U <= 320:
-        assert warp_rnnt_amd.last_lattice_kernel() == "lattice_wl"
+        assert debug.last_lattice_kernel() == "lattice_wl"
     assert torch.equal(c_ws, c_wl)
     assert torch.equal(g_ws, g_wl)
     if N * T * U <= 400_000:
@@ -144,8 +138,8 @@ def test_lost_hand_over_is_redone_by_the_single_workgroup_kernel():
     code = r'''
 import sys, numpy as np, torch
 sys.path.insert(0, %r); sys.path.insert(0, %r)
-import warp_rnnt_amd, oracle
-from warp_rnnt_amd import ops
+import oracle
+from warp_rnnt_amd import debug, ops
 from helpers import make_case, np_log_softmax32
 dev = torch.device("cuda:0")
 L = ops._lib.load()
@@ -156,7 +150,7 @@ for (N, T, U) in [(4, 500, 300), (16, 300, 130), (40, 200, 200)]:
     txn, tyn = torch.tensor(xn, device=dev), torch.tensor(yn, device=dev)
     res = {}
     for k in ("ws", "wd"):
-        warp_rnnt_amd.set_lattice("logdomain"); warp_rnnt_amd.set_logdomain_kernel(k)
+        debug.set_lattice_kernel(k)
         ws = torch.empty((L.rnnt_amd_workspace_size(N, T, U),), dtype=torch.uint8, device=dev)
         costs = torch.empty((N,), device=dev); grads = torch.empty((N, T, U, 2), device=dev)
         st = L.rnnt_amd_loss(torch.cuda.current_stream().cuda_stream, ws.data_ptr(), 1, lp2.data_ptr(), None,
@@ -190,41 +184,39 @@ def test_compact_layout_same_bits(N, T, U, V):
     labs = torch.cat([tl[n, :yn[n]] for n in range(N)]).contiguous()
     out = {}
     for k in ("ws", "wd", "wl"):
-        old_r = warp_rnnt_amd.set_lattice("logdomain")
-        old_k = warp_rnnt_amd.set_logdomain_kernel(k)
-        try:
+        with debug.lattice_kernel(k):
             x = rows.clone().requires_grad_(True)
             loss = warp_rnnt.rnnt_loss(x, labs, txn, tyn, compact=True, reduction="sum")
             loss.backward()
             torch.cuda.synchronize()
             out[k] = (loss.detach().clone(), x.grad.clone())
-        finally:
-            warp_rnnt_amd.set_lattice(old_r)
-            warp_rnnt_amd.set_logdomain_kernel(old_k)
     assert torch.equal(out["ws"][0], out["wd"][0]) and torch.equal(out["ws"][1], out["wd"][1])
     assert torch.equal(out["ws"][0], out["wl"][0]) and torch.equal(out["ws"][1], out["wl"][1])
 
 
-def test_blocks_of_sixteen_diagonals_same_bits():
-    """csrc/lattice_wd_body.h is compiled twice; the instantiation with blocks of 16 diagonals is opt-in since the end of
-    round 5 (RNNT_WD_K16_FROM_T; csrc/lattice_wd.hip says why).  It has to give the bits of the single-workgroup kernel
-    like the other one: the long shapes of SHAPES in a subprocess with the knob set."""
+@pytest.mark.parametrize("from_t", ["1", "1000000"], ids=["sixteen_everywhere", "eight_everywhere"])
+def test_both_block_sizes_same_bits(from_t):
+    """csrc/lattice_wd_body.h is compiled twice: blocks of 8 diagonals and blocks of 16, the second the choice from launch
+    bound T >= 1024 on since round 6 (RNNT_WD_K16_FROM_T overrides; csrc/lattice_wd.hip has the history).  Each has to
+    give the bits of the single-workgroup kernel at every length: short and long shapes of SHAPES in a subprocess with
+    the knob forcing one size everywhere."""
     code = r'''
 import sys
 sys.path.insert(0, %r); sys.path.insert(0, %r)
 import numpy as np, torch
-import warp_rnnt_amd, oracle
+import oracle
 from helpers import make_case, np_log_softmax32
-from warp_rnnt_amd import ops
+from warp_rnnt_amd import debug, ops
 dev = torch.device("cuda:0")
 L = ops._lib.load()
-for (N, T, U, ragged) in [(3, 1030, 40, True), (2, 1100, 70, True), (2, 1200, 300, False), (3, 1024, 129, True), (2, 1500, 17, False)]:
+for (N, T, U, ragged) in [(3, 37, 70, True), (4, 200, 65, True), (16, 150, 40, False), (5, 333, 129, True), (4, 600, 300, True), (2, 5, 130, False),
+                          (3, 1030, 40, True), (2, 1100, 70, True), (2, 1200, 300, False), (3, 1024, 129, True), (2, 1500, 17, False)]:
     logits, labels, xn, yn = make_case(1000 + N + T + U, N, T, U, 6, ragged=ragged)
     lp2 = torch.tensor(oracle.gather_f32(np_log_softmax32(logits), labels, 0), device=dev)
     txn, tyn = torch.tensor(xn, device=dev), torch.tensor(yn, device=dev)
     res = {}
     for k in ("ws", "wd"):
-        warp_rnnt_amd.set_lattice("logdomain"); warp_rnnt_amd.set_logdomain_kernel(k)
+        debug.set_lattice_kernel(k)
         ws = torch.empty((L.rnnt_amd_workspace_size(N, T, U),), dtype=torch.uint8, device=dev)
         costs = torch.empty((N,), device=dev); grads = torch.empty((N, T, U, 2), device=dev)
         st = L.rnnt_amd_loss(torch.cuda.current_stream().cuda_stream, ws.data_ptr(), 1, lp2.data_ptr(), None,
@@ -233,8 +225,8 @@ for (N, T, U, ragged) in [(3, 1030, 40, True), (2, 1100, 70, True), (2, 1200, 30
         torch.cuda.synchronize()
         res[k] = (costs, grads)
     assert torch.equal(res["ws"][0], res["wd"][0]) and torch.equal(res["ws"][1], res["wd"][1]), (N, T, U)
-print("K16_SAME_BITS_OK")
+print("BLOCK_SIZE_SAME_BITS_OK")
 ''' % (os.path.dirname(HERE), HERE)
-    env = dict(os.environ, RNNT_WD_K16_FROM_T="1024")
+    env = dict(os.environ, RNNT_WD_K16_FROM_T=from_t)
     out = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
-    assert out.returncode == 0 and b"K16_SAME_BITS_OK" in out.stdout, out.stdout.decode()[-3000:]
+    assert out.returncode == 0 and b"BLOCK_SIZE_SAME_BITS_OK" in out.stdout, out.stdout.decode()[-3000:]

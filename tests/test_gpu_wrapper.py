@@ -105,6 +105,94 @@ def test_log_softmax_then_loss_matches_fused_from_logits():
     np.testing.assert_allclose(g1.cpu().numpy(), g2.cpu().numpy(), atol=1e-4)
 
 
+def test_gather_true_takes_any_strides_like_the_reference_and_gather_false_still_raises():
+    """In the reference `log_probs.gather(dim=3, index)` (__init__.py:126) runs before CHECK_CONTIGUOUS(xs) ever sees the
+    tensor (binding.cpp:33): a transposed or sliced joint output works with gather=True and raises "xs must be contiguous"
+    with gather=False.  Same here (missing #2): values and gradients equal to the contiguous call's."""
+    import warp_rnnt
+    logits, labels, xn, yn = make_case(21, 3, 30, 17, 9, ragged=True)
+    lp = np_log_softmax32(logits)
+    base = T(lp).requires_grad_(True)
+    c0 = warp_rnnt.rnnt_loss(base, T(labels), T(xn), T(yn), gather=True, fastemit_lambda=0.01)
+    (c0 * T(np.array([1.0, 2.0, 3.0], np.float32))).sum().backward()
+    # (N,U,T,V) storage viewed as (N,T,U,V): what a joint network that builds (N,U,T,*) and transposes hands over
+    store = T(np.ascontiguousarray(lp.transpose(0, 2, 1, 3))).requires_grad_(True)
+    view = store.transpose(1, 2)
+    assert not view.is_contiguous() and view.shape == base.shape
+    c1 = warp_rnnt.rnnt_loss(view, T(labels), T(xn), T(yn), gather=True, fastemit_lambda=0.01)
+    (c1 * T(np.array([1.0, 2.0, 3.0], np.float32))).sum().backward()
+    assert torch.equal(c0, c1) and torch.equal(store.grad.transpose(1, 2), base.grad)
+    # a slice along V (a wider joint output of which the loss sees a prefix)
+    wide = T(np.concatenate([lp, np.zeros_like(lp[..., :3])], axis=-1))
+    c2 = warp_rnnt.rnnt_loss(wide[..., :9], T(labels), T(xn), T(yn), gather=True, fastemit_lambda=0.01)
+    assert torch.equal(c0, c2)
+    with pytest.raises(RuntimeError, match="xs must be contiguous"):
+        warp_rnnt.rnnt_loss(view, T(labels), T(xn), T(yn), gather=False)
+    with pytest.raises(RuntimeError, match="ys must be contiguous"):         # only log_probs went through torch.gather there
+        warp_rnnt.rnnt_loss(base, T(np.concatenate([labels, labels], 1))[:, ::2], T(xn), T(yn), gather=True)
+
+
+@pytest.mark.parametrize("N,Tm,Um,V,lam", [(3, 40, 21, 50, 0.0), (2, 700, 70, 11, 0.01), (4, 33, 9, 1500, 0.0)])
+def test_lazy_log_softmax_keeps_the_reference_call_shape_and_runs_the_fused_path(N, Tm, Um, V, lam):
+    """`rnnt_loss(log_softmax(logits), ..., gather=True)` -- benchmark.py:65-70's call -- with
+    warp_rnnt_amd.functional.log_softmax: the handle it returns computes nothing; rnnt_loss recognises it and runs the fused
+    logits -> pairs -> loss path and, in backward, logits -> d/d logits.  THE SAME BITS as
+    rnnt_loss_from_logits, forward and backward, under every reduction; the same numbers as the materialised chain; any
+    other consumer of the handle gets the log-probabilities (and their gradient flows through the log-softmax backward)."""
+    import warp_rnnt
+    from warp_rnnt_amd import functional as F2
+    from warp_rnnt_amd.fused import rnnt_loss_from_logits
+    logits, labels, xn, yn = make_case(40 + Tm, N, Tm, Um, V, ragged=True)
+    tl, txn, tyn = T(labels), T(xn), T(yn)
+    up = T(np.linspace(0.5, 1.5, N).astype(np.float32))
+    for reduction, avg in (("none", False), ("mean", True), ("sum", False)):
+        xa, xb, xc = (T(logits).requires_grad_(True) for _ in range(3))
+        handle = F2.log_softmax(xa)
+        assert isinstance(handle, F2.LazyLogSoftmax) and not handle.materialised and handle.shape == xa.shape
+        assert handle.dtype == torch.float32 and handle.is_cuda and handle.requires_grad and handle.logits is xa
+        la = warp_rnnt.rnnt_loss(handle, tl, txn, tyn, gather=True, fastemit_lambda=lam, reduction=reduction,
+                                 average_frames=avg)
+        assert not handle.materialised                               # the log-probabilities never existed
+        lb = rnnt_loss_from_logits(xb, tl, txn, tyn, fastemit_lambda=lam, reduction=reduction, average_frames=avg)
+        lc = warp_rnnt.rnnt_loss(F2.log_softmax(xc, lazy=False), tl, txn, tyn, gather=True, fastemit_lambda=lam,
+                                 reduction=reduction, average_frames=avg)
+        for l_ in (la, lb, lc):
+            (l_ * up if reduction == "none" else l_ * 1.25).sum().backward()
+        assert torch.equal(la, lb) and torch.equal(xa.grad, xb.grad)                       # bit for bit the fused entry
+        np.testing.assert_allclose(la.detach().cpu().numpy(), lc.detach().cpu().numpy(), rtol=2e-6)
+        np.testing.assert_allclose(xa.grad.cpu().numpy(), xc.grad.cpu().numpy(), atol=2e-4 if Tm > 500 else 2e-5)
+    # another consumer: the handle becomes the log-probabilities (once), with autograd through the log-softmax backward
+    xd, xe = T(logits).requires_grad_(True), T(logits).requires_grad_(True)
+    h = F2.log_softmax(xd)
+    w = T(np.random.RandomState(1).randn(*logits.shape).astype(np.float32))
+    (h * w).sum().backward()
+    assert h.materialised
+    (torch.log_softmax(xe, -1) * w).sum().backward()
+    np.testing.assert_allclose(h.detach().cpu().numpy(), torch.log_softmax(xe, -1).detach().cpu().numpy(), atol=2e-6)
+    np.testing.assert_allclose(xd.grad.cpu().numpy(), xe.grad.cpu().numpy(), atol=2e-5)
+    # both routes on one handle: the gradients add up
+    xf = T(logits).requires_grad_(True)
+    hf = F2.log_softmax(xf)
+    (warp_rnnt.rnnt_loss(hf, tl, txn, tyn, gather=True, reduction="sum") + (hf * w).sum()).backward()
+    xg = T(logits).requires_grad_(True)
+    lpg = torch.log_softmax(xg, -1)
+    (warp_rnnt.rnnt_loss(lpg, tl, txn, tyn, gather=True, reduction="sum") + (lpg * w).sum()).backward()
+    np.testing.assert_allclose(xf.grad.cpu().numpy(), xg.grad.cpu().numpy(), atol=3e-4 if Tm > 500 else 3e-5)
+    # gather=False / a leaf handle that requires grad itself: the ordinary path on materialised log-probabilities
+    h2 = F2.log_softmax(T(logits))
+    if V <= 64:
+        c_dense = warp_rnnt.rnnt_loss(h2, tl, txn, tyn, gather=False)
+        assert h2.materialised
+        c_ref = warp_rnnt.rnnt_loss(torch.log_softmax(T(logits), -1), tl, txn, tyn, gather=False)
+        np.testing.assert_allclose(c_dense.cpu().numpy(), c_ref.cpu().numpy(), rtol=2e-6)
+    h3 = F2.log_softmax(T(logits)).requires_grad_(True)
+    assert h3.is_leaf and not h3.fusable()
+    warp_rnnt.rnnt_loss(h3, tl, txn, tyn, gather=True, reduction="sum").backward()
+    lp3 = torch.log_softmax(T(logits), -1).requires_grad_(True)
+    warp_rnnt.rnnt_loss(lp3, tl, txn, tyn, gather=True, reduction="sum").backward()
+    np.testing.assert_allclose(h3.grad.cpu().numpy(), lp3.grad.cpu().numpy(), atol=2e-4 if Tm > 500 else 2e-5)
+
+
 def test_sharded_loss_single_process():
     from warp_rnnt_amd.distributed import sharded_rnnt_loss
     logits, labels, xn, yn = make_case(4, 5, 20, 7, 8, ragged=True)

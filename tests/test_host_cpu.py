@@ -43,56 +43,45 @@ def test_header_symbols_exported():
         assert re.search(r"\bT " + name + r"\b", syms), name
 
 
-def test_lattice_route_is_a_runtime_setting_and_sizes_do_not_depend_on_it():
-    """rnnt_amd_set_lattice / warp_rnnt_amd.set_lattice: host-side state only (one atomic), so it is testable here.
-    The workspace size is a function of the shape alone -- a caller may size, change the route, then call."""
+def test_the_only_setting_is_a_debug_kernel_pin_and_sizes_do_not_depend_on_it():
+    """Round 6: one arithmetic, no route setting (rnnt_amd_set_lattice and the per-call *_ex entries are gone).  What is
+    left is rnnt_amd_debug_set_lattice_kernel / warp_rnnt_amd.debug.set_lattice_kernel: host-side state only (one atomic),
+    so it is testable here.  The workspace size is a function of the shape alone."""
     import warp_rnnt_amd
+    from warp_rnnt_amd import debug
     L = warp_rnnt_amd.load()
-    start = warp_rnnt_amd.get_lattice()
-    try:
-        assert start in warp_rnnt_amd.LATTICE_ROUTES
-        sizes = {}
-        for route in ("logdomain", "pd", "auto"):
-            prev = warp_rnnt_amd.set_lattice(route)
-            assert prev in warp_rnnt_amd.LATTICE_ROUTES and warp_rnnt_amd.get_lattice() == route
-            sizes[route] = (L.rnnt_amd_workspace_size(16, 1500, 300), L.rnnt_amd_workspace_size(4, 150, 40),
-                            L.rnnt_amd_workspace_size_compact(16, 16 * 1500 * 300, 1500, 300))
-        assert sizes["logdomain"] == sizes["pd"] == sizes["auto"]
-        with warp_rnnt_amd.lattice_route("logdomain"):
-            assert warp_rnnt_amd.get_lattice() == "logdomain"
-            with warp_rnnt_amd.lattice_route("pd"):
-                assert warp_rnnt_amd.get_lattice() == "pd"
-            assert warp_rnnt_amd.get_lattice() == "logdomain"
-        assert warp_rnnt_amd.get_lattice() == "auto"
-        with pytest.raises(ValueError, match="unknown lattice route"):
-            warp_rnnt_amd.set_lattice("fast")
-        assert L.rnnt_amd_set_lattice(7) == -1 and warp_rnnt_amd.get_lattice() == "auto"   # unknown value: no change
-    finally:
-        warp_rnnt_amd.set_lattice(start)
-    # hand-over rings are reserved for every shape with more than one column block (the probability-domain kernel's
-    # up to U = 512, the distributed log-domain kernel's -- one granule per diagonal -- beyond) and for no others
+    for gone in ("rnnt_amd_set_lattice", "rnnt_amd_get_lattice", "rnnt_amd_loss_ex", "rnnt_amd_loss_compact_ex",
+                 "rnnt_amd_set_logdomain_kernel"):
+        assert not hasattr(L, gone), gone
+    syms = subprocess.check_output(["nm", "-D", "--defined-only", warp_rnnt_amd.lib_path()]).decode()
+    assert "lattice_pd" not in syms and "k_lattice_pd" not in syms          # the second arithmetic is not in the library
+    # hand-over rings are reserved for every shape with more than one column block (one granule per diagonal and boundary)
+    # and for no others
     cells = lambda n, t, u: n * t * u * 16
     assert L.rnnt_amd_workspace_size(16, 1500, 64) - cells(16, 1500, 64) < 1 << 16
-    assert L.rnnt_amd_workspace_size(16, 1500, 300) - cells(16, 1500, 300) > 1 << 20
+    assert 1 << 20 < L.rnnt_amd_workspace_size(16, 1500, 300) - cells(16, 1500, 300) < 1 << 22
     wide = L.rnnt_amd_workspace_size(2, 100, 1100) - cells(2, 100, 1100)
     assert 2 * 2 * 17 * (1199 + 8) * 8 <= wide < 1 << 20
-    # the kernel choice inside the log-domain route: the same kind of setting, and sizes do not depend on it either
+    size = L.rnnt_amd_workspace_size(16, 1500, 300)
     try:
-        assert warp_rnnt_amd.set_logdomain_kernel("wd") == "auto" and L.rnnt_amd_get_logdomain_kernel() == 2
-        assert L.rnnt_amd_workspace_size(16, 1500, 300) == sizes["auto"][0]
-        assert warp_rnnt_amd.set_logdomain_kernel("ws") == "wd"
-        assert L.rnnt_amd_set_logdomain_kernel(9) == -1 and L.rnnt_amd_get_logdomain_kernel() == 1
-        with pytest.raises(ValueError, match="unknown log-domain kernel"):
-            warp_rnnt_amd.set_logdomain_kernel("fast")
+        assert debug.set_lattice_kernel("wd") == "auto" and L.rnnt_amd_debug_get_lattice_kernel() == 2
+        assert L.rnnt_amd_workspace_size(16, 1500, 300) == size
+        assert debug.set_lattice_kernel("ws") == "wd"
+        assert L.rnnt_amd_debug_set_lattice_kernel(9) == -1 and L.rnnt_amd_debug_get_lattice_kernel() == 1
+        with debug.lattice_kernel("wl"):
+            assert debug.get_lattice_kernel() == "wl" and L.rnnt_amd_workspace_size(16, 1500, 300) == size
+        assert debug.get_lattice_kernel() == "ws"
+        with pytest.raises(ValueError, match="unknown lattice kernel"):
+            debug.set_lattice_kernel("fast")
     finally:
-        warp_rnnt_amd.set_logdomain_kernel("auto")
+        debug.set_lattice_kernel("auto")
     assert L.rnnt_amd_workspace_size_compact(4, 4 * 700 * 200, 700, 200) > L.rnnt_amd_workspace_size_compact(4, 4 * 700 * 200, 700, 64)
 
 
-def test_route_initial_value_comes_from_the_environment():
-    code = ("import sys; sys.path.insert(0, %r); import torch, warp_rnnt_amd; print(warp_rnnt_amd.get_lattice())" % ROOT)
-    for env, want in (({}, "auto"), ({"RNNT_LATTICE": "logdomain"}, "logdomain"), ({"RNNT_LATTICE": "pd"}, "pd")):
-        e = {k: v for k, v in os.environ.items() if k != "RNNT_LATTICE"}
+def test_kernel_pin_initial_value_comes_from_the_environment():
+    code = ("import sys; sys.path.insert(0, %r); import torch; from warp_rnnt_amd import debug; print(debug.get_lattice_kernel())" % ROOT)
+    for env, want in (({}, "auto"), ({"RNNT_DEBUG_LATTICE_KERNEL": "ws"}, "ws"), ({"RNNT_DEBUG_LATTICE_KERNEL": "wl"}, "wl")):
+        e = {k: v for k, v in os.environ.items() if k != "RNNT_DEBUG_LATTICE_KERNEL"}
         e.update(env)
         out = subprocess.run([sys.executable, "-c", code], env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
                              timeout=300)
@@ -470,3 +459,63 @@ def test_package_self_test_ships_the_golden_data_and_skips_cleanly_without_a_gpu
     out = subprocess.run([sys.executable, "-m", "warp_rnnt.test"], cwd=ROOT, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr[-2000:]
     assert "skipped" in out.stderr and "FAILED" not in out.stderr
+
+
+def test_rccl_debug_parser_tolerates_whatever_it_is_given():
+    """bench.py's first-contact record (n_gpus > 1): RCCL's own NCCL_DEBUG=INFO lines -> version + transport per rank.  The
+    parser must never raise and never invent: absent lines, another wording, an empty or missing file give None."""
+    import bench
+    p = bench.parse_rccl_debug
+    assert p(None) == p("") == {"version": None, "channels_via": {}, "transport": None}
+    assert p("garbage\n\x00\xff via\nvia \n NCCL version\n")["transport"] is None
+    text = ("n1:77:77 [0] NCCL INFO NCCL version 2.22.3+hip7.0\n"
+            "n1:77:99 [0] NCCL INFO Channel 00/0 : 0[0] -> 1[1] via P2P/IPC\n"
+            "n1:77:99 [0] NCCL INFO Channel 01/0 : 0[0] -> 1[1] via P2P/IPC/read\n"
+            "n1:77:99 [0] NCCL INFO Channel 02/0 : 0[0] -> 7[7] via P2P/direct pointer\n")
+    r = p(text)
+    assert r["version"] == "2.22.3+hip7.0" and r["transport"] == "P2P" and sum(r["channels_via"].values()) == 3
+    r = p(text + "n1:77:99 [0] NCCL INFO Channel 00 : 0[0] -> 1[1] via SHM/direct/direct\n")
+    assert r["transport"] == "mixed" and r["channels_via"]["SHM"] == 1
+    assert p("x NCCL INFO Channel 00/0 : 0[0] -> 1[1] [send] via NET/Socket/0")["transport"] == "NET"
+    assert p("RCCL version : 2.21.5-HEAD:abc")["version"].startswith("2.21.5")
+
+
+def test_lazy_log_softmax_handle_computes_nothing_until_somebody_looks(monkeypatch):
+    """warp_rnnt_amd.functional: the handle's mechanics on the CPU (the kernels behind it stubbed with torch's): no compute
+    at construction, one materialisation for any number of consumers, autograd through both the handle and its logits,
+    and what makes a handle fusable."""
+    from warp_rnnt_amd import functional as F2
+    calls = {"fwd": 0, "bwd": 0}
+
+    def fake_fwd(x, out=None):
+        calls["fwd"] += 1
+        return torch.log_softmax(x, -1)
+
+    def fake_bwd(g, y, grad_in=None):
+        calls["bwd"] += 1
+        return g - torch.exp(y) * g.sum(-1, keepdim=True)
+    monkeypatch.setattr(F2.ops, "log_softmax", fake_fwd)
+    monkeypatch.setattr(F2.ops, "log_softmax_backward", fake_bwd)
+    x = torch.randn(2, 3, 4, 5, requires_grad=True)
+    h = F2._LazyLogSoftmaxFn.apply(x)
+    h._src = x
+    assert isinstance(h, F2.LazyLogSoftmax) and calls == {"fwd": 0, "bwd": 0} and not h.materialised
+    assert h.shape == x.shape and h.dtype == x.dtype and h.requires_grad and h.grad_fn is not None and h.fusable()
+    assert "materialised=False" in repr(h) and calls["fwd"] == 0
+    s1, s2 = (h * 2).sum(), h[0].sum()                          # two consumers, one materialisation
+    assert calls["fwd"] == 1 and h.materialised
+    (s1 + s2).backward()
+    x2 = x.detach().clone().requires_grad_(True)
+    lp = torch.log_softmax(x2, -1)
+    ((lp * 2).sum() + lp[0].sum()).backward()
+    assert torch.allclose(x.grad, x2.grad, atol=1e-6) and calls["bwd"] >= 1
+    leaf = F2._LazyLogSoftmaxFn.apply(torch.randn(2, 3, 4, 5))
+    leaf._src = torch.zeros(())
+    assert leaf.fusable() and not leaf.requires_grad
+    leaf.requires_grad_(True)
+    assert not leaf.fusable()                                    # d/d log-probs is wanted: the ordinary path
+    m = leaf.materialise()
+    assert type(m) is torch.Tensor and m.grad_fn is not None
+    assert not F2._LazyLogSoftmaxFn.apply(torch.randn(6, 5)).fusable()      # not (N,T,U,V)
+    with pytest.raises(RuntimeError, match="fp32 tensor on the GPU"):
+        F2.log_softmax(torch.randn(2, 3))

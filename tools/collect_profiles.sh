@@ -12,7 +12,7 @@ python $R/bench.py > $OUT/bench_c4.json 2> $OUT/bench_c4.err
 python $R/bench.py --config c2 --steps 500 --warmup 20 > $OUT/bench_c2.json 2>> $OUT/bench.err
 python $R/bench.py --config c3 --steps 100 > $OUT/bench_c3.json 2>> $OUT/bench.err
 python $R/bench.py --config c5 --steps 5 --warmup 1 --no-cpu-baseline > $OUT/bench_c5.json 2>> $OUT/bench.err
-RNNT_LATTICE=pd python $R/bench.py --no-cpu-baseline > $OUT/bench_c4_pd_lattice.json 2>> $OUT/bench.err
+RNNT_WD_K16_FROM_T=1000000 python $R/bench.py --no-cpu-baseline > $OUT/bench_c4_blocks_of_8.json 2>> $OUT/bench.err
 rocprofv3 --kernel-trace --stats -d $OUT/stats_c4 -o c4 -- python $R/bench.py --steps 50 --warmup 5 --no-cpu-baseline > $OUT/bench_c4_profiled.json 2>/dev/null
 rocprofv3 --kernel-trace --stats -d $OUT/stats_c3 -o c3 -- python $R/bench.py --config c3 --steps 50 --warmup 5 --no-cpu-baseline > /dev/null 2>&1
 rocprofv3 --kernel-trace --stats -d $OUT/stats_c2 -o c2 -- python $R/bench.py --config c2 --steps 100 --warmup 5 --no-cpu-baseline > /dev/null 2>&1

@@ -1,14 +1,13 @@
 #!/usr/bin/env python
-"""Times the alpha+beta sweeps alone under every route of the in-tree library, in one process, for a list of shapes:
+"""Times the alpha+beta sweeps alone on every lattice kernel of the in-tree library, in one process, for a list of shapes:
 
-    pd   probability domain, one workgroup per column block            (csrc/lattice_pd.hip)
-    ws   log domain, one workgroup per sweep, compute + I/O wave pairs (csrc/lattice_ws.hip; U <= 512)
-    wd   log domain, one workgroup per column block ("distributed")    (csrc/lattice_wd.hip)
-    wl   log domain, one workgroup per sweep, wd's three wave roles    (csrc/lattice_wd.hip: k_lattice_wl; 64 < U <= 320)
+    ws   one workgroup per sweep, compute + I/O wave pairs (csrc/lattice_ws.hip; U <= 512)
+    wd   one workgroup per column block ("distributed")    (csrc/lattice_wd.hip; RNNT_WD_K16_FROM_T picks its block size)
+    wl   one workgroup per sweep, wd's three wave roles    (csrc/lattice_wd.hip: k_lattice_wl; 64 < U <= 320)
     auto what launch_lattice picks by shape
 
 and checks that ws, wd, wl and auto leave the same bits in the alpha / beta planes (full-length utterances, so every cell
-is live).  WARP_RNNT_AMD_LIB=<variant .so> times another build of the library (e.g. the wd_k16 variant).  HIP events around 5 back-to-back launches, 10 rounds, median / min in us.
+is live).  WARP_RNNT_AMD_LIB=<variant .so> times another build of the library.  HIP events around 5 back-to-back launches, 10 rounds, median / min in us.
 
     python tools/lattice_routes.py [N,T,U ...]
 """
@@ -20,8 +19,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
-import warp_rnnt_amd  # noqa: E402
-from warp_rnnt_amd import _lib  # noqa: E402
+from warp_rnnt_amd import _lib, debug  # noqa: E402
 
 DEFAULT = ["16,1500,64", "16,1500,128", "16,1500,300", "16,1500,512", "8,3000,500", "24,1500,300", "32,1500,300",
            "64,1500,300", "128,1500,300", "16,700,100", "16,400,100", "32,250,100", "16,150,40", "32,150,20", "64,500,100",
@@ -43,23 +41,19 @@ def run(shape, L, dev):
     plane = (cells * 4 + 255) // 256 * 256
     row = {}
     planes = {}
-    for name, route, kern in (("pd", "pd", "auto"), ("ws", "logdomain", "ws"), ("wd", "logdomain", "wd"),
-                              ("wl", "logdomain", "wl"), ("auto", "auto", "auto")):
+    for name in ("ws", "wd", "wl", "auto"):
         if name == "ws" and U > 512:
-            continue
-        if name == "pd" and (U > 512 or os.environ.get("ROUTES_NO_PD")):
             continue
         if name == "wl" and not 64 < U <= 320:
             continue
-        warp_rnnt_amd.set_lattice(route)
-        warp_rnnt_amd.set_logdomain_kernel(kern)
+        debug.set_lattice_kernel(name)
         # the pairs are consumed in place when gradients are produced: rebuild them for every route
         st = L.rnnt_amd_loss(stream, ws.data_ptr(), 1, lp2.data_ptr(), None, xn.data_ptr(), yn.data_ptr(),
                              costs.data_ptr(), grads.data_ptr(), 1, N, T, U, 2, 0, 0.0)
         assert st == 0, st
         torch.cuda.synchronize()
         planes[name] = (ws[:cells * 4].view(torch.float32).clone(), ws[plane:plane + cells * 4].view(torch.float32).clone(),
-                        float(costs.double().sum().item()), warp_rnnt_amd.last_lattice_kernel())
+                        float(costs.double().sum().item()), debug.last_lattice_kernel())
         times = []
         for rnd in range(12):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -78,10 +72,9 @@ def run(shape, L, dev):
             ok = torch.equal(planes[base][0], planes[k][0]) and torch.equal(planes[base][1], planes[k][1])
             same.append(f"{k} {'=' if ok else 'DIFFERS FROM'} {base}")
     cells_txt = " ".join(f"{k} {row[k][0]:7.1f} ({row[k][1]:6.1f})" if k in row else f"{k}       -         "
-                         for k in ("pd", "ws", "wd", "wl", "auto"))
+                         for k in ("ws", "wd", "wl", "auto"))
     print(f"N={N:4d} T={T:5d} U={U:4d}   {cells_txt}   [{', '.join(same)}; auto -> {planes['auto'][3]}]", flush=True)
-    warp_rnnt_amd.set_lattice("auto")
-    warp_rnnt_amd.set_logdomain_kernel("auto")
+    debug.set_lattice_kernel("auto")
 
 
 def main():

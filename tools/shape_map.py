@@ -52,7 +52,8 @@ def gather_line_bytes(torch, row_index, labels_of_cell, V):
 def run():
     import torch
     import warp_rnnt
-    import warp_rnnt_amd
+    import warp_rnnt_amd  # noqa: F401
+    from warp_rnnt_amd import debug
     from warp_rnnt_amd import ops
     from warp_rnnt_amd.fused import rnnt_loss_from_logits
     dev = torch.device("cuda:0")
@@ -88,7 +89,7 @@ def run():
                 j = mark()
                 torch.cuda.synchronize()
                 sections.append(dict(common, path=path, marker=i, marker_end=j, reps=REPS,
-                                     lattice=warp_rnnt_amd.last_lattice_kernel()))
+                                     lattice=debug.last_lattice_kernel()))
 
             section("log_softmax + rnnt_loss(gather=True)",
                     lambda: warp_rnnt.rnnt_loss(ops.log_softmax(xs), ys, xn, yn, gather=True))

@@ -13,7 +13,7 @@ the sweep: allowed, counted) are accumulated the same way.  A case that shows a 
 a description of what differs.
 
 Shapes (N, T, U; r = ragged lengths) -- the six-shape set:
-    16,1500,300     c4: five column blocks, k_lattice_wd with rings (blocks of 16 diagonals with RNNT_WD_K16_FROM_T <= 1500)
+    16,1500,300     c4: five column blocks, k_lattice_wd with rings, blocks of 16 diagonals (RNNT_WD_K16_FROM_T=1000000: of 8)
     12,700,180,r    three column blocks, k_lattice_wd with rings
     16,400,100      two column blocks, k_lattice_wl
     32,250,100,r    two column blocks, k_lattice_wl, ragged
@@ -59,8 +59,7 @@ def make_pairs(seed, N, T, U, ragged, dev):
 
 def child(seconds, seed):
     import torch
-    import warp_rnnt_amd
-    from warp_rnnt_amd import ops
+    from warp_rnnt_amd import debug, ops
     dev = torch.device("cuda:0")
     L = ops._lib.load()
     stream = torch.cuda.current_stream().cuda_stream
@@ -82,23 +81,23 @@ def child(seconds, seed):
         return torch.equal(a.view(torch.int32), b.view(torch.int32))
 
     cases = []
-    pinned = L.rnnt_amd_get_logdomain_kernel()
+    pinned = L.rnnt_amd_debug_get_lattice_kernel()
     for i, (N, T, U, ragged) in enumerate(shapes):
         lp2, xn, yn = make_pairs(seed * 1000 + i, N, T, U, ragged, dev)
         c = dict(N=N, T=T, U=U, lp2=lp2, xn=xn, yn=yn,
                  ws=torch.empty((L.rnnt_amd_workspace_size(N, T, U),), dtype=torch.uint8, device=dev))
         # the reference: the same entry on k_lattice_ws, once, before any load
-        L.rnnt_amd_set_logdomain_kernel(1)
+        L.rnnt_amd_debug_set_lattice_kernel(1)
         rc, rg = torch.empty((N,), device=dev), torch.empty((N, T, U, 2), device=dev)
         launch(c, rc, rg)
         torch.cuda.synchronize()
-        assert warp_rnnt_amd.last_lattice_kernel() == "lattice_ws", warp_rnnt_amd.last_lattice_kernel()
+        assert debug.last_lattice_kernel() == "lattice_ws", debug.last_lattice_kernel()
         ra, rb = (p.clone() for p in planes(c))
-        L.rnnt_amd_set_logdomain_kernel(pinned)
+        L.rnnt_amd_debug_set_lattice_kernel(pinned)
         c.update(ref=(rc, rg, ra, rb), costs=torch.empty_like(rc), grads=torch.empty_like(rg))
         launch(c, c["costs"], c["grads"])            # which kernel this case runs under the setting being soaked
         torch.cuda.synchronize()
-        c["kernel"] = warp_rnnt_amd.last_lattice_kernel()
+        c["kernel"] = debug.last_lattice_kernel()
         c["rings"] = U > 64 and c["kernel"] == "lattice_wd"      # (only the ring kernel prepares and uses the flags)
         off = L.rnnt_amd_debug_redo_offset(N, T, U)
         c["flags"] = c["ws"][off:off + 8 * N].view(torch.int32)

@@ -25,8 +25,7 @@ for sym, (res, a_) in _lib.SYMBOLS.items():
     if hasattr(L, sym):
         fn = getattr(L, sym)
         fn.restype, fn.argtypes = res, a_
-L.rnnt_amd_set_lattice(1)
-L.rnnt_amd_set_logdomain_kernel(2)
+L.rnnt_amd_debug_set_lattice_kernel(2)
 dev = torch.device("cuda:0")
 g = torch.Generator(device=dev)
 g.manual_seed(0)
@@ -37,7 +36,7 @@ costs = torch.empty((N,), device=dev)
 grads = torch.empty((N, T, U, 2), device=dev)
 ws = torch.zeros((L.rnnt_amd_workspace_size(N, T, U),), dtype=torch.uint8, device=dev)
 s = torch.cuda.current_stream().cuda_stream
-K = 16 if T >= int(os.environ.get("RNNT_WD_K16_FROM_T", str(2**31 - 1))) else 8     # (csrc/lattice_wd.hip: wd_block_diagonals)
+K = 16 if T >= int(os.environ.get("RNNT_WD_K16_FROM_T", "1024")) else 8     # (csrc/lattice_wd.hip: wd_block_diagonals)
 nA = (U + 63) // 64
 pitch = ((T + U - 1 + K - 1) // K + 2) * K
 slots = (T + U - 1) // K + 24

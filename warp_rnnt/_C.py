@@ -10,6 +10,7 @@ import warnings
 import torch
 
 from warp_rnnt_amd import ops as _ops
+from warp_rnnt_amd import _mismatch
 
 try:                     # the compiled binding (warp_rnnt_amd/csrc/binding.cpp, built by _build.build_binding)
     from . import _C_native as _native
@@ -63,10 +64,16 @@ def check_inputs(xs, ys, xn, yn):
 
 
 def _native_call(fn, xs, ys, xn, yn, blank, fastemit_lambda):
-    """One call into the compiled binding; WARP_RNNT_AMD_CHECK_MISMATCH handled as in ops.loss."""
+    """One call into the compiled binding.  The forward/backward guard (core_gather.cu:341-354): by default a look at the
+    device's sticky diagnostics words before the call (no synchronisation; what earlier kernels reported becomes a
+    RuntimeWarning -- warp_rnnt_amd/_mismatch.py); WARP_RNNT_AMD_CHECK_MISMATCH = warn | raise reads this call's own
+    flags back instead (one host synchronisation), off does neither."""
     policy = os.environ.get("WARP_RNNT_AMD_CHECK_MISMATCH", "").lower()
-    costs, grads, mismatch = fn(xs, ys, xn, yn, blank, fastemit_lambda, bool(policy))
-    if policy:
+    exact = policy in ("warn", "raise", "1", "on")
+    if xs.is_cuda:
+        _mismatch.poll(xs.device)
+    costs, grads, mismatch = fn(xs, ys, xn, yn, blank, fastemit_lambda, exact)
+    if exact:
         bad = mismatch.nonzero().flatten().tolist()          # host synchronisation (opt-in)
         if bad:
             msg = (f"rnnt_loss: forward/backward mismatch or invalid lengths for utterance(s) {bad}: "

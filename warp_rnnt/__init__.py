@@ -13,6 +13,8 @@ from typing import Optional
 import torch
 
 from . import _C as core
+from warp_rnnt_amd import _mismatch
+from warp_rnnt_amd.functional import LazyLogSoftmax
 
 __version__ = "0.7.0+amd.mi355x"
 
@@ -37,6 +39,7 @@ class RNNTLoss(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, grads_output):
+        _mismatch.poll(ctx.grads.device)      # (the forward's guard, if it fired: a memory read, no synchronisation)
         # out of place: a second backward (retain_graph) sees the same gradient again
         return (ctx.grads * _per_utterance(grads_output, ctx.grads),) + (None,) * 5
 
@@ -48,6 +51,12 @@ class RNNTLossGather(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, log_probs, labels, frames_lengths, labels_lengths, blank=0, fastemit_lambda=0.0):
+        # The reference's `log_probs.gather(dim=3, index)` (__init__.py:126) takes ANY strides and hands the native op a
+        # fresh contiguous (N,T,U,2) tensor, so a transposed or sliced joint output works with gather=True there (and
+        # raises "xs must be contiguous" with gather=False, binding.cpp:33 -- as it does here).  The native gather reads
+        # the dense tensor itself, so the strides are resolved here, where the reference resolved them.
+        if log_probs.dim() == 4 and not log_probs.is_contiguous():
+            log_probs = log_probs.contiguous()
         costs, pairs_grad = core.rnnt_loss_gather(xs=log_probs, ys=labels, xn=frames_lengths,
                                                   yn=labels_lengths, blank=blank,
                                                   fastemit_lambda=fastemit_lambda)
@@ -58,6 +67,7 @@ class RNNTLossGather(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grads_output):
         labels, xn, yn, vocab, blank = ctx.meta
+        _mismatch.poll(ctx.pairs_grad.device)
         scale = grads_output.reshape(-1).to(ctx.pairs_grad).contiguous()
         dense = core.rnnt_loss_gather_backward(scale, ctx.pairs_grad, labels, xn, yn, vocab, blank)
         return (dense,) + (None,) * 5
@@ -126,6 +136,9 @@ def rnnt_loss(log_probs: torch.FloatTensor,
     ``log_probs``       fp32, contiguous, on the GPU, already log-softmaxed over the last axis:
                         ``(N, T, U, V)`` (T frames, U = longest label sequence + 1, V symbols incl. blank)
                         or, with ``compact=True``, the ragged ``(sum_n T_n*(U_n+1), V)`` packing.
+                        With ``gather=True`` any strides are accepted (as the reference's ``torch.gather`` accepts them),
+                        and the lazy result of ``warp_rnnt_amd.functional.log_softmax(logits)`` is fused with: same
+                        value and gradients, log-softmax + gather + loss in one read of the logits.
     ``labels``          int32 ``(N, U-1)`` (``(sum_n U_n,)`` when compact).
     ``frames_lengths``  int32 ``(N,)`` -- T_n.
     ``labels_lengths``  int32 ``(N,)`` -- U_n.
@@ -148,6 +161,20 @@ def rnnt_loss(log_probs: torch.FloatTensor,
     _check_call(average_frames, reduction, blank, gather, labels, frames_lengths, labels_lengths)
     if not compact and (max_frames is not None or max_labels is not None):
         raise ValueError("max_frames / max_labels are launch bounds of the compact layout: pass compact=True with them")
+
+    if isinstance(log_probs, LazyLogSoftmax):
+        # `rnnt_loss(warp_rnnt_amd.functional.log_softmax(logits), ..., gather=True)`: the reference's call shape
+        # (benchmark.py:65-70), served by the fused logits -> loss -> d/d logits path: the log-probabilities never
+        # materialise.  Everything else the handle is used for makes it an ordinary tensor first.
+        if gather and not compact and log_probs.fusable():
+            from warp_rnnt_amd.fused import RNNTLossFromLogits
+            logits = log_probs.logits
+            costs = RNNTLossFromLogits.apply(logits if logits.is_contiguous() else logits.contiguous(), labels,
+                                             frames_lengths, labels_lengths, blank, fastemit_lambda)
+            if average_frames:
+                costs = costs / frames_lengths.to(costs)
+            return _reduce(costs, reduction)
+        log_probs = log_probs.materialise()
 
     if compact:
         wants_grad = log_probs.requires_grad and torch.is_grad_enabled()

@@ -13,8 +13,7 @@ from . import _isa_check
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libwarp_rnnt_amd.so")
-SOURCES = ["api.hip", "lattice.hip", "lattice_ws.hip", "lattice_wd.hip", "lattice_pd.hip", "grads.hip", "prologue.hip",
-           "expand.hip"]
+SOURCES = ["api.hip", "lattice.hip", "lattice_ws.hip", "lattice_wd.hip", "grads.hip", "prologue.hip", "expand.hip"]
 HEADERS = ["common.h", "kernels.h", "lattice_step.h", "lattice_wd_body.h", "grads_cell.h",
            os.path.join("..", "..", "include", "warp_rnnt_amd.h")]
 ARCH = "gfx950"
@@ -59,13 +58,11 @@ def _stale(target, deps):
 # A/B builds for the parity table (tests/test_gpu_baseline_sizes.py, profiles/r02_parity_errors.json);
 # select one at run time with WARP_RNNT_AMD_LIB=<path> (see _lib.lib_path).
 VARIANTS = {
-    # log-domain lattice, hardware exp2/log2 lse (the round-1 default), single-role kernel
-    "logdomain": ["-DRNNT_LATTICE_LOGDOMAIN"],
-    # the same with ocml expf/log1pf -- the reference's own lse (core.cu:26-39) bit for bit, 4x slower
-    "precise": ["-DRNNT_LATTICE_LOGDOMAIN", "-DRNNT_LATTICE_LEGACY", "-DRNNT_PRECISE_LIBM"],
+    # the single-role kernel with ocml expf/log1pf in the chain -- the reference's own lse (core.cu:26-39) bit for bit, 4x slower
+    "precise": ["-DRNNT_LATTICE_LEGACY", "-DRNNT_PRECISE_LIBM"],
     # hand-over waits that give up at once: every column block that catches up with its neighbour flags its sweep
-    # for the log-domain kernel (the "producer lost" path, which never triggers otherwise)
-    "short_spin": ["-DRNNT_PD_SPIN_LIMIT=0", "-DRNNT_WD_SPIN_LIMIT=0"],
+    # for the kernel behind (the "producer lost" path, which never triggers otherwise)
+    "short_spin": ["-DRNNT_WD_SPIN_LIMIT=0"],
     # A/B of k_lattice_wl's wave placement: six waves in column-block-major order / compute waves at raised priority
     "wl_nopad": ["-DRNNT_WL_PAD=0"],
     "wl_noprio": ["-DRNNT_WL_PRIO=0"],

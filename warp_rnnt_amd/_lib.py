@@ -35,7 +35,6 @@ SYMBOLS = {
     "rnnt_amd_workspace_mismatch_offset": (_sz, [_i, _i, _i]),
     "rnnt_amd_debug_redo_offset": (_sz, [_i, _i, _i]),
     "rnnt_amd_loss": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f]),
-    "rnnt_amd_loss_ex": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _i]),
     "rnnt_amd_expand_grads": (_i, [_vp] * 7 + [_i] * 6),
     "rnnt_amd_logits_backward": (_i, [_vp] * 6 + [_i] * 5),
     "rnnt_amd_log_softmax": (_i, [_vp, _vp, _vp, _i64, _i]),
@@ -43,23 +42,21 @@ SYMBOLS = {
     "rnnt_amd_gather": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i]),
     "rnnt_amd_workspace_size_compact": (_sz, [_i, _i64, _i, _i]),
     "rnnt_amd_loss_compact": (_i, [_vp] * 11 + [_i, _i64, _i, _i, _i, _i, _f]),
-    "rnnt_amd_loss_compact_ex": (_i, [_vp] * 11 + [_i, _i64, _i, _i, _i, _i, _f, _i]),
     "rnnt_amd_workspace_size_compact_bounded": (_sz, [_i, _i64, _i, _i]),
     "rnnt_amd_loss_compact_bounded": (_i, [_vp] * 4 + [_i64] + [_vp] * 5 + [_i, _i64, _i, _i, _i, _i, _f]),
     "rnnt_amd_compact_scatter_grads": (_i, [_vp] * 6 + [_i64, _i, _i, _i]),
     "rnnt_amd_compact_offsets": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp]),
     "rnnt_amd_debug_lattice_only": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i]),
     "rnnt_amd_debug_gather_only": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i]),
-    "rnnt_amd_set_lattice": (_i, [_i]),
-    "rnnt_amd_get_lattice": (_i, []),
-    "rnnt_amd_set_logdomain_kernel": (_i, [_i]),
-    "rnnt_amd_get_logdomain_kernel": (_i, []),
+    "rnnt_amd_debug_set_lattice_kernel": (_i, [_i]),
+    "rnnt_amd_debug_get_lattice_kernel": (_i, []),
+    "rnnt_amd_mismatch_flag": (ctypes.POINTER(ctypes.c_uint), [_i]),
     "rnnt_amd_debug_last_lattice_kernel": (_i, []),
     "rnnt_amd_version": (_i, []),
 }
 
 
-ABI_VERSION = 105   # rnnt_amd_version() of the library these argument lists belong to
+ABI_VERSION = 106   # rnnt_amd_version() of the library these argument lists belong to
 
 
 class RNNTStatusError(RuntimeError):

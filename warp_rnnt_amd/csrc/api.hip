@@ -37,7 +37,7 @@ struct Workspace {
     float* ll;
     int* mismatch;
     int* redo;       // (2N,) hand-over between the two lattice kernels, followed by the work-item counter
-    unsigned long long* mail;   // boundary-column rings of the probability-domain lattice kernel (kernels.h)
+    unsigned long long* mail;   // boundary-column rings of k_lattice_wd (kernels.h)
 };
 
 size_t carve(void* base, int N, int T, int U, Workspace* w) {
@@ -69,17 +69,15 @@ bool dims_ok(int N, int T, int U) {
 
 extern "C" {
 
-int rnnt_amd_version(void) { return 105; }
+int rnnt_amd_version(void) { return 106; }
 
-int rnnt_amd_set_lattice(int route) { return set_lattice_route(route); }
+int rnnt_amd_debug_set_lattice_kernel(int kernel) { return set_lattice_kernel_override(kernel); }
 
-int rnnt_amd_get_lattice(void) { return lattice_route(); }
-
-int rnnt_amd_set_logdomain_kernel(int kernel) { return set_logdomain_kernel(kernel); }
-
-int rnnt_amd_get_logdomain_kernel(void) { return logdomain_kernel(); }
+int rnnt_amd_debug_get_lattice_kernel(void) { return lattice_kernel_override(); }
 
 int rnnt_amd_debug_last_lattice_kernel(void) { return last_lattice_kernel(); }
+
+volatile unsigned* rnnt_amd_mismatch_flag(int device) { return mismatch_words(device, true); }
 
 size_t rnnt_amd_workspace_size(int N, int T, int U) {
     if (!dims_ok(N, T, U)) return 0;
@@ -136,7 +134,6 @@ rnntStatus_t run_warp_rnnt(rnntStream_t stream, unsigned int* counts, float* alp
         if (launch_gather(stream, log_probs, labels, grads, N, T, U, V, blank, true) != hipSuccess)
             return RNNT_STATUS_WARP_FAILED;
         LatticeArgs la{grads, nullptr, xn, yn, alphas, betas, ll, T, U, 2, 0, nullptr, redo, redo ? redo + 2 * N : nullptr, mail};
-        la.route = ROUTE_LOGDOMAIN;
         if (launch_lattice(stream, la, N, LOAD_SKEWED) != hipSuccess) return RNNT_STATUS_WARP_FAILED;
         // gradient pairs in place of the log-prob pairs (coalesced both ways), parked in the caller's alphas / betas --
         // dead by then -- and expanded from there into whole dense rows, zeros included: the staging area is
@@ -179,7 +176,6 @@ rnntStatus_t run_warp_rnnt_gather(rnntStream_t stream, unsigned int* counts, flo
         // the sweeps run on the single-workgroup log-domain kernel.
         if (launch_reskew(stream, log_probs, grads, N, T, U) != hipSuccess) return RNNT_STATUS_WARP_FAILED;
         LatticeArgs la{grads, nullptr, xn, yn, alphas, betas, ll, T, U, 2, 0};
-        la.route = ROUTE_LOGDOMAIN;
         if (launch_lattice(stream, la, N, LOAD_SKEWED) != hipSuccess) return RNNT_STATUS_WARP_FAILED;
         // gradient pairs in place of the log-prob pairs, parked in alphas / betas (dead by then), turned back into the
         // row-major layout through LDS tiles: three coalesced passes (33 + 35 + 30 us at N=16, T=1500, U=300) instead
@@ -203,15 +199,6 @@ rnntStatus_t rnnt_amd_loss(rnntStream_t stream, void* workspace, int input_kind,
                            const int* labels, const int* xn, const int* yn, float* costs, float* grads,
                            int grads_kind, int N, int T, int U, int V, int blank,
                            float fastemit_lambda) {
-    return rnnt_amd_loss_ex(stream, workspace, input_kind, input, labels, xn, yn, costs, grads, grads_kind, N, T, U, V,
-                            blank, fastemit_lambda, RNNT_LATTICE_DEFAULT);
-}
-
-rnntStatus_t rnnt_amd_loss_ex(rnntStream_t stream, void* workspace, int input_kind, const float* input,
-                              const int* labels, const int* xn, const int* yn, float* costs, float* grads,
-                              int grads_kind, int N, int T, int U, int V, int blank,
-                              float fastemit_lambda, int lattice) {
-    if (lattice != RNNT_LATTICE_DEFAULT && (lattice < ROUTE_AUTO || lattice > ROUTE_PD)) return RNNT_STATUS_INVALID_ARGUMENT;
     if (!dims_ok(N, T, U) || !workspace) return RNNT_STATUS_INVALID_ARGUMENT;
     if (reinterpret_cast<uintptr_t>(workspace) % ALIGN) return RNNT_STATUS_INVALID_ARGUMENT;
     const bool gathered_in = input_kind == RNNT_IN_LOG_PROBS_GATHERED;
@@ -245,7 +232,6 @@ rnntStatus_t rnnt_amd_loss_ex(rnntStream_t stream, void* workspace, int input_ki
 
     // 2. alpha / beta sweeps (2N workgroups, concurrent)
     LatticeArgs la{w.ws2, nullptr, xn, yn, w.alphas, w.betas, w.ll, T, U, 2, 0, nullptr, w.redo, w.redo + 2 * N, w.mail};
-    la.route = lattice == RNNT_LATTICE_DEFAULT ? lattice_route() : lattice;
     if (launch_lattice(stream, la, N, LOAD_SKEWED) != hipSuccess) return RNNT_STATUS_WARP_FAILED;
 
     // 3. gradients + costs (+ guard).  For a dense result the pairs are produced in place in the
@@ -287,7 +273,6 @@ rnntStatus_t rnnt_amd_debug_lattice_only(rnntStream_t stream, void* workspace, c
     Workspace w;
     carve(workspace, N, T, U, &w);
     LatticeArgs la{w.ws2, nullptr, xn, yn, w.alphas, w.betas, w.ll, T, U, 2, 0, nullptr, w.redo, w.redo + 2 * N, w.mail};
-    la.route = lattice_route();
     if (launch_lattice(stream, la, N, LOAD_SKEWED) != hipSuccess) return RNNT_STATUS_WARP_FAILED;
     return RNNT_STATUS_SUCCESS;
 }
@@ -357,16 +342,6 @@ rnntStatus_t rnnt_amd_loss_compact(rnntStream_t stream, void* workspace, const f
                                    const int* label_offsets, float* costs, float* grads2, int64_t* loc,
                                    int N, int64_t STU, int Tmax, int Umax, int V, int blank,
                                    float fastemit_lambda) {
-    return rnnt_amd_loss_compact_ex(stream, workspace, xs, ys, xn, yn, cell_offsets, label_offsets, costs, grads2, loc, N,
-                                    STU, Tmax, Umax, V, blank, fastemit_lambda, RNNT_LATTICE_DEFAULT);
-}
-
-rnntStatus_t rnnt_amd_loss_compact_ex(rnntStream_t stream, void* workspace, const float* xs, const int* ys,
-                                      const int* xn, const int* yn, const int64_t* cell_offsets,
-                                      const int* label_offsets, float* costs, float* grads2, int64_t* loc,
-                                      int N, int64_t STU, int Tmax, int Umax, int V, int blank,
-                                      float fastemit_lambda, int lattice) {
-    if (lattice != RNNT_LATTICE_DEFAULT && (lattice < ROUTE_AUTO || lattice > ROUTE_PD)) return RNNT_STATUS_INVALID_ARGUMENT;
     if (!compact_dims_ok(N, STU, Tmax, Umax) || !workspace || V < 1 || blank < 0 || blank >= V)
         return RNNT_STATUS_INVALID_ARGUMENT;
     if (reinterpret_cast<uintptr_t>(workspace) % ALIGN) return RNNT_STATUS_INVALID_ARGUMENT;
@@ -379,7 +354,6 @@ rnntStatus_t rnnt_amd_loss_compact_ex(rnntStream_t stream, void* workspace, cons
                               blank, STU) != hipSuccess)
         return RNNT_STATUS_PROLOGUE_FAILED;
     LatticeArgs la{ws2, nullptr, xn, yn, alphas, betas, ll, Tmax, Umax, 2, 0, cell_offsets, w.redo, w.redo + 2 * N, w.mail};
-    la.route = lattice == RNNT_LATTICE_DEFAULT ? lattice_route() : lattice;
     if (launch_lattice(stream, la, N, LOAD_SKEWED) != hipSuccess) return RNNT_STATUS_WARP_FAILED;
     GradArgs ga{ws2, nullptr, xn, yn, alphas, betas, ll, grads2 ? grads2 : ws2, costs, mismatch,
                 Tmax, Umax, 2, 0, fastemit_lambda, cell_offsets};
@@ -531,7 +505,6 @@ void run_warp_rnnt_compact(unsigned int* counts, float* alphas, float* betas, co
         if (e != hipSuccess) { compact_fail(RNNT_STATUS_PROLOGUE_FAILED, "run_warp_rnnt_compact", costs, N, e); return; }
         LatticeArgs ls{grads, nullptr, ixn, iyn, alphas, betas, ll, (int)T, (int)U, 2, 0};
         ls.offs32 = memPref;
-        ls.route = ROUTE_LOGDOMAIN;
         e = launch_lattice(nullptr, ls, (int)N, LOAD_SKEWED);
         if (e != hipSuccess) { compact_fail(RNNT_STATUS_WARP_FAILED, "run_warp_rnnt_compact", costs, N, e); return; }
         GradArgs gs{grads, nullptr, ixn, iyn, alphas, betas, ll, grads, costs, nullptr, (int)T, (int)U, 2, 0, fastemit_lambda};

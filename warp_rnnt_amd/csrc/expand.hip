@@ -110,7 +110,7 @@ struct GradRows {      // the dense forward result computed straight from the pl
     // (small lattices, whose planes sit in L2: the cell's seven dwords are scattered reads here, one lane per row)
     const float2* lp2; const float* alphas; const float* betas; const float* ll;
     const int* labels; const int* xn; const int* yn; float* costs; int* mismatch;
-    int T, U, V, blank; float fastemit_lambda;
+    int T, U, V, blank; float fastemit_lambda; unsigned* sticky;
     __device__ __forceinline__ ExpandCell operator()(unsigned cell) const {
         const unsigned frame = cell / (unsigned)U;
         const int u = (int)(cell - frame * (unsigned)U);
@@ -123,6 +123,7 @@ struct GradRows {      // the dense forward result computed straight from the pl
         if (t == 0 && u == 0) {
             costs[n] = utt_cost(guard, len.ok);
             if (mismatch) mismatch[n] = guard.bad ? 1 : 0;
+            if (guard.bad) report_guard(sticky, (int)n, xn[n], yn[n], guard, len.ok);
         }
         int r = t + u;
         r = r >= T ? r % T : r;
@@ -255,7 +256,7 @@ hipError_t launch_grads_dense(hipStream_t stream, const GradArgs& a, float* dens
     if (cells64 == 0 || a.V == 0) return hipSuccess;
     if (is_compact(a)) return hipErrorNotSupported;
     const GradRows rows{reinterpret_cast<const float2*>(a.lp), a.alphas, a.betas, a.ll, a.labels, a.xn, a.yn, a.costs,
-                        a.mismatch, a.T, a.U, a.V, a.blank, a.fastemit_lambda};
+                        a.mismatch, a.T, a.U, a.V, a.blank, a.fastemit_lambda, mismatch_words_of(stream)};
     return launch_rows(stream, rows, dense, (unsigned)cells64, a.V, a.blank);
 }
 

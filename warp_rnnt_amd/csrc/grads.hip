@@ -13,6 +13,9 @@
 // along t).  Threads walk the lattice in diagonal-major order, so alpha,
 // beta[t+1,u], beta[t,u+1] (= next diagonal, columns u and u+1) and the
 // workspace log-probs are all coalesced row reads.
+#include <atomic>
+#include <cstring>
+
 #include "common.h"
 #include "grads_cell.h"
 #include "kernels.h"
@@ -27,6 +30,7 @@ __global__ void __launch_bounds__(256) k_grads(const GradArgs a) {
         if (blockIdx.x == 0 && threadIdx.x == 0) {
             a.costs[n] = __builtin_nanf("");
             if (a.mismatch) a.mismatch[n] = 1;
+            report_guard(a.sticky, n, a.xn[n], a.yn[n], UttGuard{0.0f, 0.0f, true}, false);
         }
         return;
     }
@@ -46,6 +50,7 @@ __global__ void __launch_bounds__(256) k_grads(const GradArgs a) {
     if (idx == 0) {
         a.costs[n] = utt_cost(guard, len.ok);
         if (a.mismatch) a.mismatch[n] = bad ? 1 : 0;
+        if (bad) report_guard(a.sticky, n, a.xn[n], a.yn[n], guard, len.ok);
     }
     if (!in) return;
 
@@ -102,8 +107,38 @@ static hipError_t launch_grads_w(hipStream_t stream, const GradArgs& a, dim3 gri
     return hipGetLastError();
 }
 
-hipError_t launch_grads(hipStream_t stream, const GradArgs& a, int N, int loader, int writer) {
+// ---- the sticky diagnostics words (kernels.h) ----
+namespace {
+constexpr int MAX_DEVICES = 64, WORDS = 16;     // (8 used; a 64-byte line per device)
+std::atomic<unsigned*> g_words{nullptr};
+}
+unsigned* mismatch_words(int device, bool allocate) {
+    if (device < 0 || device >= MAX_DEVICES) return nullptr;
+    unsigned* base = g_words.load(std::memory_order_acquire);
+    if (!base && allocate) {
+        void* p = nullptr;
+        if (hipHostMalloc(&p, sizeof(unsigned) * WORDS * MAX_DEVICES, hipHostMallocPortable | hipHostMallocMapped) != hipSuccess) {
+            (void)hipGetLastError();
+            return nullptr;
+        }
+        memset(p, 0, sizeof(unsigned) * WORDS * MAX_DEVICES);
+        unsigned* expected = nullptr;
+        if (g_words.compare_exchange_strong(expected, static_cast<unsigned*>(p), std::memory_order_acq_rel)) base = static_cast<unsigned*>(p);
+        else { (void)hipHostFree(p); base = expected; }      // another thread was first
+    }
+    return base ? base + (size_t)device * WORDS : nullptr;
+}
+unsigned* mismatch_words_of(hipStream_t stream) {
+    if (!g_words.load(std::memory_order_acquire)) return nullptr;      // (the common case until somebody asks: no runtime call)
+    int dev = -1;
+    if (hipStreamGetDevice(stream, &dev) != hipSuccess && hipGetDevice(&dev) != hipSuccess) return nullptr;
+    return mismatch_words(dev, false);
+}
+
+hipError_t launch_grads(hipStream_t stream, const GradArgs& a0, int N, int loader, int writer) {
     if (N <= 0) return hipSuccess;
+    GradArgs a = a0;
+    a.sticky = mismatch_words_of(stream);
     const dim3 grid(((unsigned)(a.T * a.U) + 255u) / 256u, (unsigned)N);
     if (is_compact(a)) {   // compact layout (a.T, a.U = maxima): packed pairs out
         if (loader == LOAD_ROWMAJOR2) {   // row-major packed pairs in (core.h shims)

@@ -16,32 +16,18 @@ struct LatticeArgs {
     int T, U, V, blank;   // V/blank: LOAD_DENSE only
     const int64_t* offs;  // compact layout: (N+1,) cell offset of each utterance's (T_n, U_n) plane;
                           // nullptr = padded (N,T,U) planes
-    int* redo;            // (2N,) [2n+dir]: written by the probability-domain kernel (non-zero = inputs outside the
-                          // range it can represent, or a lost hand-over), read by the log-domain kernel launched
-                          // behind it (0 = nothing to do); nullptr = log-domain kernel only
-    int* queue;           // work-item counter of the probability-domain kernel; MUST be redo + 2N (zeroed together);
+    int* redo;            // (2N,) [2n+dir]: set by k_lattice_wd when a hand-over between column blocks timed out (bit 1),
+                          // read by the single-workgroup kernel launched behind it (0 = nothing to do); nullptr = the
+                          // kernels that need no flags only
+    int* queue;           // work-item counter of k_lattice_wd; MUST be redo + 2N (zeroed together);
                           // queue[1] is its launch counter (never zeroed: any start value will do)
-    unsigned long long* mail;  // its hand-over rings between column blocks (pd_mail_bytes), needed when U > 64
-    int mail_blocks;      // filled in by launch_lattice_pd
-    unsigned epoch;       // filled in by launch_lattice_pd
+    unsigned long long* mail;  // its hand-over rings between column blocks (wd_mail_bytes), needed when U > 64
+    unsigned epoch;       // filled in by launch_lattice_wd
     const unsigned* offs32;  // compact layout with the reference's 32-bit offsets (run_warp_rnnt_compact); used when
                              // offs is null
     int beta_only;        // compact shim, required_grad = false: the alpha sweep is skipped (its buffer aliases betas)
-    int route;            // LatticeRoute of this call (diagonal-major loader only); 0 = ROUTE_AUTO
 };
 
-// Which arithmetic sweeps the lattice of a diagonal-major call.  Per call: api.hip copies the process-wide setting
-// (rnnt_amd_set_lattice; initial value from the environment variable RNNT_LATTICE) into LatticeArgs::route.
-enum LatticeRoute : int {
-    ROUTE_AUTO = 0,       // probability domain where it is the faster kernel (long lattices), log domain elsewhere
-    ROUTE_LOGDOMAIN = 1,  // the reference's arithmetic: lse per cell in fp32 (lattice_ws.hip / lattice.hip)
-    ROUTE_PD = 2          // probability domain (lattice_pd.hip) wherever it is supported (padded layout, U <= 512)
-};
-int lattice_route();              // current setting
-int set_lattice_route(int route); // returns the previous setting, or -1 for an unknown value (nothing changes)
-// true when launch_lattice may hand this shape to the probability-domain kernel under SOME route: the workspace
-// then reserves its hand-over rings (a function of the shape only, so that the size never depends on the setting)
-bool pd_shape_supported(int T, int U);
 __host__ __device__ inline bool is_compact(const LatticeArgs& a) { return a.offs || a.offs32; }
 __device__ inline size_t compact_base(const LatticeArgs& a, int n) { return a.offs ? (size_t)a.offs[n] : (size_t)a.offs32[n]; }
 
@@ -60,7 +46,14 @@ struct GradArgs {
     float fastemit_lambda;
     const int64_t* offs;  // as LatticeArgs
     const unsigned* offs32;
+    unsigned* sticky;     // the device's sticky diagnostics words (filled in by launch_grads / launch_grads_dense)
 };
+// Eight words of pinned host memory per device that the gradient kernels write when a forward/backward guard fires
+// (grads_cell.h: report_guard).  mismatch_words(device, true) allocates the table on first use (one hipHostMalloc per
+// process, never freed; not during stream capture); mismatch_words_of(stream) = the words of the stream's device, or
+// nullptr while nobody has asked for them.
+unsigned* mismatch_words(int device, bool allocate);
+unsigned* mismatch_words_of(hipStream_t stream);
 __host__ __device__ inline bool is_compact(const GradArgs& a) { return a.offs || a.offs32; }
 __device__ inline size_t compact_base(const GradArgs& a, int n) { return a.offs ? (size_t)a.offs[n] : (size_t)a.offs32[n]; }
 
@@ -68,40 +61,34 @@ __device__ inline size_t compact_base(const GradArgs& a, int n) { return a.offs 
 // a.blank of the dense tensor; a.grads unused): for lattices whose planes sit in L2
 hipError_t launch_grads_dense(hipStream_t stream, const GradArgs& a, float* dense, int N);
 hipError_t launch_lattice(hipStream_t stream, const LatticeArgs& a, int N, int loader);
-// wave-specialised log-domain variant (diagonal-major loader only); hipErrorNotSupported when U > 512.
-// With a.redo set only the (utterance, direction) pairs flagged there are swept.
+// ONE arithmetic -- the reference's: one fp32 lse per cell in its operation order -- and several kernels that put the same
+// instructions on the chain and give the same bits (tests/test_gpu_wd.py); launch_lattice picks by shape.
+// lattice_ws.hip: compute + I/O wave pairs, all column blocks of a sweep in one workgroup (diagonal-major loader only);
+// hipErrorNotSupported when U > 512.  With a.redo set only the (utterance, direction) pairs flagged there are swept.
 hipError_t launch_lattice_ws(hipStream_t stream, const LatticeArgs& a, int N);
-// probability-domain variant (lattice_pd.hip; diagonal-major loader; needs a.redo, a.queue and -- for U > 64 --
-// a.mail of pd_mail_bytes(N,T,U) bytes); hipErrorNotSupported when they are missing
-hipError_t launch_lattice_pd(hipStream_t stream, const LatticeArgs& a, int N);
-size_t pd_mail_bytes(int N, int T, int U);
-// distributed log-domain variant (lattice_wd.hip; diagonal-major loader, padded or 64-bit compact; one workgroup per
-// 64-column block, any U); needs a.redo, a.queue and -- for U > 64 -- a.mail of wd_mail_bytes(N,T,U) bytes;
-// hipErrorNotSupported when they are missing.  Bit-identical to launch_lattice_ws.
+// lattice_wd.hip: one three-wave workgroup per 64-column block, boundary columns through L2 rings (diagonal-major loader,
+// padded or 64-bit compact; any U); needs a.redo, a.queue and -- for U > 64 -- a.mail of wd_mail_bytes(N,T,U) bytes;
+// hipErrorNotSupported when they are missing.
 hipError_t launch_lattice_wd(hipStream_t stream, const LatticeArgs& a, int N);
 size_t wd_mail_bytes(int N, int T, int U);
 // ... and its single-workgroup form (lattice_wd.hip: k_lattice_wl): all column blocks of a sweep as waves of one
 // workgroup, boundary columns through LDS; needs nothing but the planes (no flags, no rings), padded or compact with
-// either offset width, honours a.redo and a.beta_only.  hipErrorNotSupported beyond wl_max_blocks() column blocks.
-// Bit-identical to the other two.
+// either offset width, honours a.redo and a.beta_only.  hipErrorNotSupported beyond max_blocks (<= 5) column blocks.
 hipError_t launch_lattice_wl(hipStream_t stream, const LatticeArgs& a, int N, int max_blocks);
-int wl_max_blocks();   // what launch_lattice lets it take by itself; set_logdomain_kernel(3) lets it take all it can (5)
-// what a workspace reserves for the hand-over rings of either kernel (a function of the shape only)
-inline size_t lattice_mail_bytes(int N, int T, int U) {
-    const size_t p = pd_mail_bytes(N, T, U), w = wd_mail_bytes(N, T, U);
-    return p > w ? p : w;
-}
-// In front of every launch of a kernel that hands boundary columns over through L2 rings (lattice_pd.hip owns the
+int wl_max_blocks();   // what launch_lattice lets it take by itself (RNNT_WL_MAX_BLOCKS, default 5)
+// what a workspace reserves for the hand-over rings (a function of the shape only)
+inline size_t lattice_mail_bytes(int N, int T, int U) { return wd_mail_bytes(N, T, U); }
+// In front of every launch of the kernel that hands boundary columns over through L2 rings (lattice_wd.hip owns the
 // per-device launch counter): clears n_flags words at `flags` (redo flags + queue head), stores the next value of the
 // launch counter at flags[n_flags] and zeroes ring_bytes (a multiple of 16) at `rings`.
 hipError_t launch_ring_prepare(hipStream_t stream, int* flags, int n_flags, void* rings, size_t ring_bytes);
 unsigned next_launch_epoch();     // host part of the launch epoch: random start, +1 per call
-// Which kernel serves the log-domain route where several can (same bits either way): 0 = by shape, 1 = single workgroup
-// per sweep (lattice_ws.hip), 2 = one workgroup per column block (lattice_wd.hip), 3 = its single-workgroup form
-// (k_lattice_wl) wherever it fits.  Initial value from the environment variable RNNT_LOGDOMAIN_KERNEL=ws|wd|wl.
-int last_lattice_kernel();        // what the calling thread's last launch_lattice ran: 1 ws, 2 wd, 3 pd, 4 single-role, 5 wl (0 none yet)
-int logdomain_kernel();
-int set_logdomain_kernel(int k);  // 0 by shape, 1 ws, 2 wd, 3 wl (single-workgroup form of wd); returns the previous setting, or -1
+// DEBUG / A-B ONLY: pin the kernel where several can serve (same bits whichever runs): 0 = by shape, 1 = lattice_ws.hip,
+// 2 = lattice_wd.hip, 3 = k_lattice_wl wherever it fits.  Initial value from the environment variable
+// RNNT_DEBUG_LATTICE_KERNEL=ws|wd|wl.  One process-wide atomic; nothing in the product sets it.
+int last_lattice_kernel();        // what the calling thread's last launch_lattice ran: 1 ws, 2 wd, 4 single-role, 5 wl (0 none yet)
+int lattice_kernel_override();
+int set_lattice_kernel_override(int k);  // returns the previous setting, or -1 for an unknown value (nothing changes)
 hipError_t launch_grads(hipStream_t stream, const GradArgs& a, int N, int loader, int writer);
 
 // prologue / epilogue streaming kernels

@@ -24,11 +24,10 @@
 //     block ahead; alphas/betas are written in the same diagonal-major layout
 //     with coalesced stores.
 //   Critical path: (T_n + U_n - 1) + K*(waves-1) dependent lse steps.
-#include <cstdlib>
-#include <type_traits>
-
+#include <algorithm>
 #include <atomic>
 #include <cstdlib>
+#include <type_traits>
 
 #include "common.h"
 #include "kernels.h"
@@ -454,26 +453,6 @@ __global__ void __launch_bounds__(MAXW * WAVE) k_lattice(const LatticeArgs a) {
         sweep<LOADER, false, COMPACT>(a, n, mail, trash);
 }
 
-namespace {
-int route_from_env() {
-    const char* v = getenv("RNNT_LATTICE");
-    if (v && v[0] == 'l') return ROUTE_LOGDOMAIN;
-    if (v && v[0] == 'p') return ROUTE_PD;
-    return ROUTE_AUTO;
-}
-std::atomic<int>& route_setting() {
-    static std::atomic<int> r{route_from_env()};
-    return r;
-}
-}  // namespace
-
-int lattice_route() { return route_setting().load(std::memory_order_relaxed); }
-
-int set_lattice_route(int route) {
-    if (route < ROUTE_AUTO || route > ROUTE_PD) return -1;
-    return route_setting().exchange(route, std::memory_order_relaxed);
-}
-
 // compute units of the stream's device (one query per process and device; 256 on MI355X): the kernels with one
 // workgroup per column block want CUs of their own for them
 static int device_cus(hipStream_t stream) {
@@ -490,21 +469,16 @@ static int device_cus(hipStream_t stream) {
     return n;
 }
 
-bool pd_shape_supported(int T, int U) {
-    (void)T;
-    return (U + WAVE - 1) / WAVE <= 8;     // the log-domain kernel behind it must be able to redo a sweep (U <= 512)
-}
-
 namespace {
-int logdomain_kernel_from_env() {
-    const char* v = getenv("RNNT_LOGDOMAIN_KERNEL");
+int kernel_override_from_env() {
+    const char* v = getenv("RNNT_DEBUG_LATTICE_KERNEL");
     if (v && v[0] == 'w' && v[1] == 's') return 1;
     if (v && v[0] == 'w' && v[1] == 'd') return 2;
     if (v && v[0] == 'w' && v[1] == 'l') return 3;
     return 0;
 }
-std::atomic<int>& logdomain_kernel_setting() {
-    static std::atomic<int> r{logdomain_kernel_from_env()};
+std::atomic<int>& kernel_override_setting() {
+    static std::atomic<int> r{kernel_override_from_env()};
     return r;
 }
 
@@ -530,11 +504,11 @@ hipError_t launch_single(hipStream_t stream, const LatticeArgs& a, int N, int lo
 static thread_local int g_last_kernel = 0;
 int last_lattice_kernel() { return g_last_kernel; }
 
-int logdomain_kernel() { return logdomain_kernel_setting().load(std::memory_order_relaxed); }
+int lattice_kernel_override() { return kernel_override_setting().load(std::memory_order_relaxed); }
 
-int set_logdomain_kernel(int k) {
+int set_lattice_kernel_override(int k) {
     if (k < 0 || k > 3) return -1;
-    return logdomain_kernel_setting().exchange(k, std::memory_order_relaxed);
+    return kernel_override_setting().exchange(k, std::memory_order_relaxed);
 }
 
 hipError_t launch_lattice(hipStream_t stream, const LatticeArgs& a, int N, int loader) {
@@ -544,11 +518,11 @@ hipError_t launch_lattice(hipStream_t stream, const LatticeArgs& a, int N, int l
 #ifndef RNNT_LATTICE_LEGACY
     if (loader == LOAD_SKEWED) {
         const int nA = (a.U + WAVE - 1) / WAVE;
-        // the kernels that hand boundary columns over through L2 rings need the flags, the work queue and the rings
+        // the kernel that hands boundary columns over through L2 rings needs the flags, the work queue and the rings
         // (compact layout: the native entry's 64-bit cell offsets; a.T / a.U are then the launch bounds Tmax / Umax)
         const bool ring_ok = a.redo && a.queue && !a.offs32 && (nA == 1 || a.mail);
-        // ... and behind them the single-workgroup log-domain kernel for the sweeps they flagged (normally none:
-        // its workgroups read one flag and return)
+        // ... and behind it the single-workgroup kernel for the sweeps it flagged (normally none: its workgroups read
+        // one flag and return)
         auto redo_behind = [&]() {
 #ifdef RNNT_PROBE_NO_REDO_LAUNCH   // timing probe only: what the (normally idle) kernel behind costs
             return hipSuccess;
@@ -556,76 +530,54 @@ hipError_t launch_lattice(hipStream_t stream, const LatticeArgs& a, int N, int l
             const hipError_t e = launch_lattice_ws(stream, a, N);
             return e != hipErrorNotSupported ? e : launch_single(stream, a, N, loader);
         };
-#ifndef RNNT_LATTICE_LOGDOMAIN
-        // Probability-domain sweep, one workgroup per 64-column block (lattice_pd.hip): only when the caller asks for
-        // it (route "pd": closer to exact arithmetic on long lattices), wherever it is supported
-        // (U <= 512 because the log-domain kernel behind it must be able to redo a sweep).  Until round 4 it was
-        // also what `auto` took for long lattices of small batches, because it was the fastest kernel there (N=16,
-        // T=1500, U=300: 117 us against 157 for lattice_ws.hip); lattice_wd.hip closes that gap with the reference's
-        // arithmetic (121 us), so the default no longer trades the reference's numerics -- and results that do not
-        // depend on the batch shape -- for 4 us.
-        // The route is a per-call setting (LatticeArgs::route <- rnnt_amd_set_lattice(); the environment variable
-        // RNNT_LATTICE=logdomain|pd only provides its initial value).
-        const bool pd_ok = ring_ok && pd_shape_supported(a.T, a.U);
-        if (a.route == ROUTE_PD && pd_ok) {
-            const hipError_t e = launch_lattice_pd(stream, a, N);
-            g_last_kernel = 3;
-            if (e == hipSuccess) return redo_behind();
-            if (e != hipErrorNotSupported) return e;
-        }
-#endif
-        // Log domain.  Two kernels, the same bits: lattice_ws.hip (all column blocks of a sweep in one workgroup; one
-        // pass covers U <= 512) and lattice_wd.hip (one workgroup per column block, boundary columns through L2).
-        // Which one, measured on MI355X (tools/lattice_routes.py, profiles/r04_lattice_routes.txt; us per alpha+beta
-        // launch, ws / wd): N=16, T=1500: U=64 93/88, U=128 113/103, U=300 156/122, U=512 210/145; T=3000 U=500
-        // (N=8) 372/222; U=300 by batch: N=32 159/128, N=48 175/156, N=64 204/220, N=128 306/424; T=1000 U=200:
-        // N=64 97/94, N=128 130/184; T=500 U=100: N=64 47/49; T=400 U=100 (N=16) 40/42, T=150 U=40 16/20.
-        // The distributed kernel wins while its column blocks find CUs of their own (its loader's LDS-DMA pieces
-        // queue up behind each other when five workgroups share a CU) and the sweep is long enough to recover two
-        // extra launches (ring preparation in front, the idle redo kernel behind).
-        const int kern = logdomain_kernel();
-        // (round 5, after the hand-written blocks, ws / wd / wl: two column blocks -- the single-workgroup form wl at every
-        //  size: N=16, T=1500, U=128 116 / 83 / 82, T=700, U=100 61 / 48 / 45, T=400 42 / 35 / 31, N=32, T=250 32 / 30 / 25,
-        //  N=64, T=300, U=128 39 / 36 / 30; three and more: wd while the chip has CUs for its workgroups and the sweep
-        //  is long: N=16, T=1500, U=300 161 / 102 / 128, N=32, T=1000, U=200 100 / 72 / 75; N=32, T=500, U=200 64 / 52 / 51;
-        //  full chips: N=64, T=1500, U=300 199 / 192 / 189, N=128 307 / 414 / 335 -- profiles/r05_lattice_routes.txt)
+        // One arithmetic (the reference's: one fp32 lse per cell, core_gather.cu:22-35,106-126), three kernels with the same
+        // instructions on the chain and the same bits: lattice_ws.hip (all column blocks of a sweep in one workgroup of
+        // compute + I/O wave pairs; one pass covers U <= 512), lattice_wd.hip (one three-wave workgroup per column block,
+        // boundary columns through L2) and its single-workgroup form k_lattice_wl (boundary columns through LDS).
+        // Which one, measured on MI355X (tools/lattice_routes.py, profiles/r05_lattice_routes.txt; us per alpha+beta launch,
+        // ws / wd / wl): two column blocks -- wl at every size: N=16, T=1500, U=128 116 / 83 / 82, T=700, U=100 61 / 48 / 45,
+        // T=400 42 / 35 / 31, N=32, T=250 32 / 30 / 25, N=64, T=300, U=128 39 / 36 / 30; three and more: wd while the chip has
+        // CUs for its workgroups and the sweep is long enough to recover two extra launches (ring preparation in front, the
+        // idle redo kernel behind): N=16, T=1500, U=300 161 / 102 / 128, N=32, T=1000, U=200 100 / 72 / 75; N=32, T=500, U=200
+        // 64 / 52 / 51; full chips: N=64, T=1500, U=300 199 / 192 / 189, N=128 307 / 414 / 335.
+        // (Until round 5 a probability-domain kernel, lattice_pd.hip, could be chosen here -- another arithmetic, closer to
+        // fp64 on long lattices; retired in round 6: slower than wd at c4 since the hand-written blocks, and not the
+        // reference's numbers.  profiles/HISTORY.md keeps its measurements.)
+        const int kern = lattice_kernel_override();      // debug / A-B only: 0 by shape, 1 ws, 2 wd, 3 wl
         bool use_wd = ring_ok && (long long)2 * N * nA <= 2ll * device_cus(stream) && a.T >= 640 && nA >= 3;
         if (nA > ws::MAXA_HOST) use_wd = ring_ok;             // wider than one workgroup sweeps: column blocks or stripes
-        if (kern == 1) use_wd = false;
+        if (kern == 1 || kern == 3) use_wd = false;
         if (kern == 2) use_wd = ring_ok;
         // One column block per sweep (U <= 64): nothing is handed over, so the distributed kernel needs neither the ring
         // preparation in front nor the redo kernel behind -- a plain launch of its three-wave workgroups (LDS-DMA loader,
         // store-only storer, warm instruction cache), faster than lattice_ws.hip's compute + I/O wave pair at every size
         // (us, ws / wd: N=16, T=150, U=40 16.1 / 15.0; N=32, T=150, U=20 15.1 / 13.7; N=256, T=150, U=40 19.4 / 16.6;
         // N=32, U=50: T=250 22.5 / 21.0, T=500 36.8 / 33.6, T=1000 64.8 / 58.6; N=256, T=500 42.7 / 34.5; T=1500, U=64
-        // 93 / 84; profiles/r04_lattice_routes_single_block.txt).  RNNT_WD_LONE_FROM_T=<T>: only from that T on (A/B).
-        static const int wd_lone_t = getenv("RNNT_WD_LONE_FROM_T") ? atoi(getenv("RNNT_WD_LONE_FROM_T")) : 0;
-        if (nA == 1 && kern != 1 && (kern == 2 || a.T >= wd_lone_t)) {
+        // 93 / 84; profiles/r04_lattice_routes_single_block.txt).
+        if (nA == 1 && kern != 1) {
             const hipError_t e = launch_lattice_wd(stream, plain, N);
-            g_last_kernel = 2;
-            if (e != hipErrorNotSupported) return e;
+            if (e != hipErrorNotSupported) { g_last_kernel = 2; return e; }
         }
-        if (use_wd && kern != 3) {
+        if (use_wd) {
             const hipError_t e = launch_lattice_wd(stream, a, N);
-            g_last_kernel = 2;
-            if (e == hipSuccess) return redo_behind();
+            if (e == hipSuccess) { g_last_kernel = 2; return redo_behind(); }
             if (e != hipErrorNotSupported) return e;
         }
-        // Everything else that fits: the single-workgroup form of the same kernel (k_lattice_wl, round 5: three waves per
-        // column block, LDS-DMA loader, hand-written compute blocks, boundary columns through LDS), up to
-        // wl_max_blocks() column blocks.  us per alpha+beta launch, lattice_ws.hip / this (tools/lattice_routes.py,
-        // profiles/r05_lattice_routes.txt).  Needs nothing but the planes, so it also serves the callers without flags
-        // and rings (the reference-named C entry points, 32-bit compact offsets).
-        if (kern != 1 && nA >= 2) {
+        // Everything else that fits: the single-workgroup form of the same kernel (k_lattice_wl: three waves per column
+        // block, LDS-DMA loader, hand-written compute blocks, boundary columns through LDS), up to wl_max_blocks() column
+        // blocks.  Needs nothing but the planes, so it also serves the callers without flags and rings (the
+        // reference-named C entry points, 32-bit compact offsets).  Not when wd is pinned (kern == 2): a pinned A/B run
+        // must measure the kernel it names or fall through to ws.
+        if (kern != 1 && kern != 2 && nA >= 2) {
             // (by itself: two column blocks always, up to five while one workgroup per sweep leaves CUs idle -- beyond
-            //  ~100 utterances lattice_ws.hip's ten waves per workgroup pack the chip better than fifteen)
-            const int by_shape = (nA <= 2 || N <= 96) ? wl_max_blocks() : 2;
-            const hipError_t e = launch_lattice_wl(stream, plain, N, kern == 3 ? 5 : by_shape);
+            //  ~100 utterances lattice_ws.hip's ten waves per workgroup pack the chip better than fifteen; pinned (3):
+            //  all it can take, still under RNNT_WL_MAX_BLOCKS -- 0 there means "never chosen", pinned or not)
+            const int by_shape = (nA <= 2 || N <= 96) ? wl_max_blocks() : std::min(2, wl_max_blocks());
+            const hipError_t e = launch_lattice_wl(stream, plain, N, kern == 3 ? wl_max_blocks() : by_shape);
             if (e != hipErrorNotSupported) { g_last_kernel = 5; return e; }
         }
         const hipError_t e = launch_lattice_ws(stream, plain, N);
-        g_last_kernel = 1;
-        if (e != hipErrorNotSupported) return e;
+        if (e != hipErrorNotSupported) { g_last_kernel = 1; return e; }
     }
 #endif
     g_last_kernel = 4;

@@ -8,11 +8,11 @@
 //
 // 1. WHERE the column blocks run.  In lattice_ws.hip they share a workgroup, hence a CU, and all meet at every
 //    barrier.  Here a column block is a workgroup of its own (three waves), wherever the dispatcher puts it, and the
-//    boundary column travels through L2 the way lattice_pd.hip's does:
+//    boundary column travels through L2:
 //      * ring: one 8-byte granule {fp32 value, 32-bit tag} per diagonal and (sweep, boundary); the producer's storer
 //        wave publishes the 8 granules of a block with one agent-scope (sc1) store instruction the interval after the
 //        compute wave produced them; tag = launch epoch ^ hash(ring) ^ hash(diagonal), never 0, and the rings are
-//        zeroed in front of every launch (launch_ring_prepare): a granule validates only if THIS launch wrote it;
+//        zeroed in front of every launch (launch_ring_prepare, below): a granule validates only if THIS launch wrote it;
 //      * the consumer's loader wave fetches the granules of a block DLOAD intervals ahead (LDS-DMA, like the pairs),
 //        checks the tags when the block is due, and only if the producer is not there yet polls (after letting it get
 //        LAG blocks further ahead, so that the following look-ahead fetches hit).  No flag, no fence, no back-pressure:
@@ -45,6 +45,7 @@
 #include <algorithm>
 #include <atomic>
 #include <cstdlib>
+#include <random>
 #include <type_traits>
 
 #include "common.h"
@@ -64,17 +65,57 @@ namespace rnnt {
 #undef RNNT_WD_NS
 #undef RNNT_WD_KK
 
-// Blocks of 16 diagonals: measured faster from ~1000 frames on (tools/lattice_routes.py, us per alpha+beta launch, 8 / 16:
-// N=16, T=1500: U=64 68.7 / 64.5, U=300 102.4 / 100.2, U=512 123.8 / 122.6; T=700, U=100 48.2 / 48.8; T=150, U=40 13.2 / 13.7)
-// and for most of round 5 the choice from launch bound T >= 1024 on.  Not the default: with three processes sharing the
-// GPU (tools/wd_soak.py) this instantiation was where the storer's dry run -- reloads left in flight into registers the
-// compiler reused (lattice_wd_body.h: one_block) -- showed as lost hand-overs and rare wrong plane values, so it was
-// switched off while the cause was unknown, and the round's profiles are of the 8-diagonal default.  With the cause fixed
-// it ran 340 000 launches clean under the same load; it stays opt-in until somebody re-measures:
-// RNNT_WD_K16_FROM_T=<T> turns the 16-diagonal blocks on from that launch bound T (same bits).
+// Blocks of 16 diagonals from launch bound T >= 1024 on, blocks of 8 below (tools/lattice_routes.py, us per alpha+beta launch,
+// 8 / 16: N=16, T=1500: U=64 68.7 / 64.5, U=300 102.4 / 100.2, U=512 123.8 / 122.6; T=700, U=100 48.2 / 48.8; T=150, U=40
+// 13.2 / 13.7; round 6, whole c4 step in bench.py: 0.8306 / 0.8219 ms).  History: the choice for most of round 5, then
+// switched off at its end -- with several processes sharing the GPU (tools/wd_soak.py) this instantiation was where the
+// storer's dry run, reloads left in flight into registers the compiler reused (lattice_wd_body.h: one_block), showed as
+// lost hand-overs and rare wrong plane values -- and opt-in while the fix was two commits old.  Re-qualified in round 6:
+// the reload check is part of the build, the end-of-block wait holds the refilled registers as operands, and the soak
+// record (profiles/r06_wd_soak.txt: millions of launches under three and six processes, every launch compared with
+// k_lattice_ws's bits) has no mismatch and no lost hand-over on either block size.
+// RNNT_WD_K16_FROM_T=<T> moves the threshold (1: blocks of 16 everywhere; a huge T: blocks of 8 everywhere; same bits).
 static int wd_block_diagonals(int T) {
-    static const int from_t = getenv("RNNT_WD_K16_FROM_T") ? atoi(getenv("RNNT_WD_K16_FROM_T")) : 0x7fffffff;
+    static const int from_t = getenv("RNNT_WD_K16_FROM_T") ? atoi(getenv("RNNT_WD_K16_FROM_T")) : 1024;
     return T >= from_t ? 16 : 8;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Ring preparation (until round 5 in lattice_pd.hip, whose probability-domain kernel introduced the protocol).
+// The library's launch counter of this device: module-scope device memory (zero when the code object is loaded,
+// never part of anybody's workspace), so it cannot be recycled, scribbled over or left uninitialised, and every
+// REPLAY of a captured graph advances it too -- kernel arguments are frozen at capture time, and with a frozen
+// epoch the granules of the previous replay would carry this replay's tags.
+// ---------------------------------------------------------------------------------------------------------------
+__device__ unsigned g_launch_counter;
+
+// In front of every launch: clears the redo flags and the queue head (n words), hands the next value of the launch
+// counter to the kernel (p[n]) and zeroes the hand-over rings (mail_vec 16-byte words; tag 0 never validates), so
+// that nothing the workspace held before -- it is caller scratch with unspecified contents -- can be taken for a
+// granule of this launch.  The clear is 1 % of the bytes the sweeps move.
+__global__ void __launch_bounds__(256) k_prepare(int* p, int n, uint4* mail, size_t mail_vec) {
+    if (blockIdx.x == 0) {
+        for (int i = threadIdx.x; i < n; i += 256) p[i] = 0;
+        if (threadIdx.x == 0) p[n] = (int)(atomicAdd(&g_launch_counter, 1u) + 1u);
+    }
+    const uint4 z = make_uint4(0, 0, 0, 0);
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < mail_vec; i += (size_t)gridDim.x * 256) mail[i] = z;
+}
+
+unsigned next_launch_epoch() {
+    // granules of earlier launches (same buffer) never validate.  Random start so that a recycled allocation of
+    // another process does not either; the device-side counter (k_prepare) is added in the kernel.
+    static std::atomic<unsigned> epoch{std::random_device{}()};
+    return epoch.fetch_add(1, std::memory_order_relaxed) + 1;
+}
+
+hipError_t launch_ring_prepare(hipStream_t stream, int* flags, int n_flags, void* rings, size_t ring_bytes) {
+    // the flags (2N ints) and the queue head are contiguous in the workspace (api.hip: carve).  One tiny kernel:
+    // hipMemsetAsync of these few bytes becomes two fill kernels of ~5 us each.
+    const size_t mail_vec = ring_bytes / 16;
+    const unsigned prep_blocks = (unsigned)std::min<size_t>(512, std::max<size_t>(1, mail_vec / (256 * 8)));
+    k_prepare<<<prep_blocks, 256, 0, stream>>>(flags, n_flags, reinterpret_cast<uint4*>(rings), mail_vec);
+    return hipGetLastError();
 }
 
 size_t wd_mail_bytes(int N, int T, int U) {

@@ -4,7 +4,7 @@ import warnings
 
 import torch
 
-from . import _lib
+from . import _lib, _mismatch
 from ._lib import (GRADS_DENSE, GRADS_GATHERED, GRADS_GATHERED_DIAGONAL, GRADS_NONE,  # noqa: F401
                    IN_LOG_PROBS_DENSE, IN_LOG_PROBS_GATHERED, IN_LOGITS_DENSE, STATUS_NAMES)
 
@@ -26,31 +26,18 @@ def _check(status):
 
 def _mismatch_policy():
     """WARP_RNNT_AMD_CHECK_MISMATCH = warn | raise: read the guard flags back after every loss call
-    (one host synchronisation) -- the counterpart of the reference's device-side WARNING printf
-    (core_gather.cu:345-349).  Unset (default): no read-back, the flags stay on the device."""
+    (one host synchronisation: exact and immediate).  Unset (default): no read-back; the counterpart of the
+    reference's device-side WARNING printf (core_gather.cu:345-349) is the sticky per-device word the gradient kernel
+    writes and _mismatch.poll() turns into a RuntimeWarning at the next call or backward.  off: neither."""
     return os.environ.get("WARP_RNNT_AMD_CHECK_MISMATCH", "").lower()
 
 
-LATTICE_ROUTES = {None: -1, "default": -1, "auto": 0, "logdomain": 1, "pd": 2}
-
-
-def _route(lattice):
-    try:
-        return LATTICE_ROUTES[lattice]
-    except KeyError:
-        raise ValueError(f"unknown lattice route {lattice!r}: expected one of 'auto', 'logdomain', 'pd' or None "
-                         "(None = the process-wide default, warp_rnnt_amd.set_lattice)") from None
-
-
-def loss(input, labels, xn, yn, input_kind, grads_kind, blank=0, fastemit_lambda=0.0, return_mismatch=False,
-         lattice=None):
+def loss(input, labels, xn, yn, input_kind, grads_kind, blank=0, fastemit_lambda=0.0, return_mismatch=False):
     """costs (N,), grads (layout per grads_kind; None for GRADS_NONE) [, mismatch (N,) int32].
     Tensors must be validated by the caller (contiguous, fp32/int32, same GPU).  ``mismatch[n]`` is 1
     where the forward/backward consistency guard zeroed an utterance's gradients (or its lengths were
-    out of range).  ``lattice``: the arithmetic of the sweeps for THIS call -- ``"auto"`` / ``"logdomain"`` (the
-    reference's) or ``"pd"`` (probability domain); ``None`` = the process-wide default of
-    :func:`warp_rnnt_amd.set_lattice`.  A per-call route reads and writes no shared state (``rnnt_amd_loss_ex``)."""
-    route = _route(lattice)
+    out of range); without asking for it the same event surfaces as a RuntimeWarning a little later, with no
+    synchronisation (warp_rnnt_amd/_mismatch.py)."""
     L = _lib.load()
     N, T, U, V = input.shape
     dev = input.device
@@ -76,11 +63,14 @@ def loss(input, labels, xn, yn, input_kind, grads_kind, blank=0, fastemit_lambda
             raise RuntimeError("rnnt_loss status 5 (RNNT_STATUS_INVALID_ARGUMENT): unsupported sizes "
                                f"N={N} T={T} U={U}")
         ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
-        st = L.rnnt_amd_loss_ex(_stream(dev), ws.data_ptr(), input_kind, input.data_ptr(), _ptr(labels),
-                                xn.data_ptr(), yn.data_ptr(), costs.data_ptr(), _ptr(grads), grads_kind,
-                                N, T, U, V, blank, float(fastemit_lambda), route)
+        _mismatch.poll(dev)          # (what an EARLIER call's kernels reported; sets the device's words up at first use)
+        st = L.rnnt_amd_loss(_stream(dev), ws.data_ptr(), input_kind, input.data_ptr(), _ptr(labels),
+                             xn.data_ptr(), yn.data_ptr(), costs.data_ptr(), _ptr(grads), grads_kind,
+                             N, T, U, V, blank, float(fastemit_lambda))
         _check(st)
         policy = _mismatch_policy()
+        if policy not in ("warn", "raise", "1", "on"):
+            policy = ""
         if return_mismatch or policy:
             off = L.rnnt_amd_workspace_mismatch_offset(N, T, U)
             mismatch = ws[off:off + 4 * N].view(torch.int32).clone()
@@ -155,8 +145,7 @@ def gather(log_probs, labels, blank=0):
     return out
 
 
-def loss_compact(xs, ys, xn, yn, blank=0, fastemit_lambda=0.0, required_grad=True, max_frames=None, max_labels=None,
-                 lattice=None):
+def loss_compact(xs, ys, xn, yn, blank=0, fastemit_lambda=0.0, required_grad=True, max_frames=None, max_labels=None):
     """Compact (ragged packed) layout: xs (STU,V), ys (sum yn,), xn/yn (N,).
     Returns (costs (N,), grads (STU,2) or None, loc (STU,) int64).
 
@@ -164,17 +153,14 @@ def loss_compact(xs, ys, xn, yn, blank=0, fastemit_lambda=0.0, required_grad=Tru
     reference's binding need the sums; the reference does four).  With ``max_frames >= max(xn)`` and ``max_labels >=
     max(yn)`` supplied by the caller: none -- offsets, maxima and checks stay on the device (``rnnt_amd_loss_compact_
     bounded``), the call can be captured into a HIP graph; a batch that does not fit the bounds or the tensors' sizes
-    comes back with NaN costs and zero gradients instead of an exception.  ``lattice``: as in :func:`loss` (a per-call
-    route is not available together with the bounds: that entry takes the process-wide default)."""
-    route = _route(lattice)
-    if route != -1 and max_frames is not None:
-        raise ValueError("lattice= cannot be combined with max_frames / max_labels")
+    comes back with NaN costs and zero gradients instead of an exception."""
     L = _lib.load()
     dev = xs.device
     N = xn.shape[0]
     STU, V = xs.shape
     if (max_frames is None) != (max_labels is None):
         raise ValueError("max_frames and max_labels go together")
+    _mismatch.poll(dev)
     with torch.cuda.device(dev):
         costs = torch.empty((N,), dtype=torch.float32, device=dev)
         loc = torch.empty((STU,), dtype=torch.int64, device=dev)
@@ -207,10 +193,10 @@ def loss_compact(xs, ys, xn, yn, blank=0, fastemit_lambda=0.0, required_grad=Tru
         if ws_bytes == 0:
             raise RuntimeError("rnnt_loss status 5 (RNNT_STATUS_INVALID_ARGUMENT): unsupported sizes")
         ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
-        st = L.rnnt_amd_loss_compact_ex(_stream(dev), ws.data_ptr(), xs.data_ptr(), _ptr(ys), xn.data_ptr(),
-                                        yn.data_ptr(), offs.data_ptr(), loffs.data_ptr(), costs.data_ptr(),
-                                        _ptr(grads), loc.data_ptr(), N, STU, tmax, umax, V, blank,
-                                        float(fastemit_lambda), route)
+        st = L.rnnt_amd_loss_compact(_stream(dev), ws.data_ptr(), xs.data_ptr(), _ptr(ys), xn.data_ptr(),
+                                     yn.data_ptr(), offs.data_ptr(), loffs.data_ptr(), costs.data_ptr(),
+                                     _ptr(grads), loc.data_ptr(), N, STU, tmax, umax, V, blank,
+                                     float(fastemit_lambda))
         _check(st)
     return costs, grads, loc
 
