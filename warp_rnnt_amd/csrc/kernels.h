@@ -16,17 +16,37 @@ struct LatticeArgs {
     int T, U, V, blank;   // V/blank: LOAD_DENSE only
     const int64_t* offs;  // compact layout: (N+1,) cell offset of each utterance's (T_n, U_n) plane;
                           // nullptr = padded (N,T,U) planes
-    int* redo;            // (2N,) [2n+dir]: set by k_lattice_wd when a hand-over between column blocks timed out (bit 1),
-                          // read by the single-workgroup kernel launched behind it (0 = nothing to do); nullptr = the
-                          // kernels that need no flags only
-    int* queue;           // work-item counter of k_lattice_wd; MUST be redo + 2N (zeroed together);
+    int* redo;            // (4N + 2 words with queue) [2n+dir]: set by k_lattice_wd when a hand-over between column blocks
+                          // timed out (bit 1); [2N + 2n+dir]: how many column blocks of the sweep have finished -- the last
+                          // one redoes a flagged sweep itself (lattice_wd_body.h).  The single-workgroup kernels sweep
+                          // only the flagged sweeps when given one (nothing in the library does that any more);
+                          // nullptr = the kernels that need no flags only
+    int* queue;           // work-item counter of k_lattice_wd; MUST be redo + 4N (zeroed together);
                           // queue[1] is its launch counter (never zeroed: any start value will do)
     unsigned long long* mail;  // its hand-over rings between column blocks (wd_mail_bytes), needed when U > 64
     unsigned epoch;       // filled in by launch_lattice_wd
     const unsigned* offs32;  // compact layout with the reference's 32-bit offsets (run_warp_rnnt_compact); used when
                              // offs is null
     int beta_only;        // compact shim, required_grad = false: the alpha sweep is skipped (its buffer aliases betas)
+    int prepared;         // the rings and flags of this call have been prepared by the kernel in front (RingPrep below):
+                          // launch_lattice_wd does not launch k_prepare
 };
+
+// What k_prepare does in front of every launch of the ring kernel, as a parcel that the PRODUCER of the call's pair plane
+// -- the gather / re-layout kernel that runs in front of the sweeps anyway -- can carry out at the tail of its own
+// workgroups (round 6: one 5 us launch less on the dense and gathered routes; the routes whose producer does not take
+// a parcel keep the launch).  flags == nullptr: nothing to do.
+struct RingPrep {
+    int* flags;           // n_flags words cleared (redo flags, queue head); flags[n_flags] receives the next value of ...
+    int n_flags;
+    unsigned* counter;    // ... the device's launch counter (device address of lattice_wd.hip's g_launch_counter)
+    uint4* rings;         // ring_vec 16-byte words zeroed
+    size_t ring_vec;
+};
+// Fills `prep` and returns true when launch_lattice(stream, a, N, loader) is going to run the ring kernel on a.redo /
+// a.queue / a.mail -- the caller hands the parcel to its producer and sets a.prepared; false (prep untouched, all zero):
+// no ring kernel, or the counter's address is not available for this stream's device -- launch_lattice prepares itself.
+bool lattice_ring_prep(hipStream_t stream, const LatticeArgs& a, int N, int loader, RingPrep* prep);
 
 __host__ __device__ inline bool is_compact(const LatticeArgs& a) { return a.offs || a.offs32; }
 __device__ inline size_t compact_base(const LatticeArgs& a, int n) { return a.offs ? (size_t)a.offs[n] : (size_t)a.offs32[n]; }
@@ -71,6 +91,7 @@ hipError_t launch_lattice_ws(hipStream_t stream, const LatticeArgs& a, int N);
 // hipErrorNotSupported when they are missing.
 hipError_t launch_lattice_wd(hipStream_t stream, const LatticeArgs& a, int N);
 size_t wd_mail_bytes(int N, int T, int U);
+bool wd_redoes_in_kernel();   // (compile-time RNNT_WD_INKERNEL_REDO: no kernel is launched behind k_lattice_wd)
 // ... and its single-workgroup form (lattice_wd.hip: k_lattice_wl): all column blocks of a sweep as waves of one
 // workgroup, boundary columns through LDS; needs nothing but the planes (no flags, no rings), padded or compact with
 // either offset width, honours a.redo and a.beta_only.  hipErrorNotSupported beyond max_blocks (<= 5) column blocks.
@@ -82,6 +103,9 @@ inline size_t lattice_mail_bytes(int N, int T, int U) { return wd_mail_bytes(N, 
 // per-device launch counter): clears n_flags words at `flags` (redo flags + queue head), stores the next value of the
 // launch counter at flags[n_flags] and zeroes ring_bytes (a multiple of 16) at `rings`.
 hipError_t launch_ring_prepare(hipStream_t stream, int* flags, int n_flags, void* rings, size_t ring_bytes);
+// the parcel for a launch of the ring kernel on `a` (flags, queue and rings as launch_lattice_wd would prepare them), or
+// false when there is nothing to prepare / the launch counter's address cannot be had for the stream's device
+bool wd_ring_prep(hipStream_t stream, const LatticeArgs& a, int N, RingPrep* prep);
 unsigned next_launch_epoch();     // host part of the launch epoch: random start, +1 per call
 // DEBUG / A-B ONLY: pin the kernel where several can serve (same bits whichever runs): 0 = by shape, 1 = lattice_ws.hip,
 // 2 = lattice_wd.hip, 3 = k_lattice_wl wherever it fits.  Initial value from the environment variable
@@ -96,8 +120,9 @@ hipError_t launch_log_softmax(hipStream_t stream, const float* x, float* out, in
 hipError_t launch_log_softmax_backward(hipStream_t stream, const float* dy, const float* y, float* dx,
                                        int64_t rows, int V);
 hipError_t launch_gather(hipStream_t stream, const float* log_probs, const int* labels, float* out2,
-                         int N, int T, int U, int V, int blank, bool skewed);
-hipError_t launch_reskew(hipStream_t stream, const float* lp2_rowmajor, float* ws2, int N, int T, int U);
+                         int N, int T, int U, int V, int blank, bool skewed, const RingPrep* prep = nullptr);
+hipError_t launch_reskew(hipStream_t stream, const float* lp2_rowmajor, float* ws2, int N, int T, int U,
+                         const RingPrep* prep = nullptr);
 // diagonal-major pairs (b == nullptr: float2 plane at a; else two float planes) -> row-major (N,T,U,2)
 hipError_t launch_unskew(hipStream_t stream, const float* a, const float* b, float* out2_rowmajor, int N, int T, int U);
 hipError_t launch_split_pairs(hipStream_t stream, const float* pairs, float* a, float* b, size_t cells);

@@ -50,9 +50,17 @@
 
 #include "common.h"
 #include "kernels.h"
+#include "lattice_single.h"
 #include "lattice_step.h"
 
 namespace rnnt {
+
+// 1: a sweep flagged by a lost hand-over is redone INSIDE k_lattice_wd by the last of its workgroups to finish
+// (lattice_wd_body.h); 0: by a kernel launched behind it on every call (rounds 4-5: k_lattice_ws, idle 5 us per step)
+#ifndef RNNT_WD_INKERNEL_REDO
+#define RNNT_WD_INKERNEL_REDO 1
+#endif
+bool wd_redoes_in_kernel() { return RNNT_WD_INKERNEL_REDO != 0; }
 
 #define RNNT_WD_NS wd8
 #define RNNT_WD_KK 8
@@ -118,6 +126,23 @@ hipError_t launch_ring_prepare(hipStream_t stream, int* flags, int n_flags, void
     return hipGetLastError();
 }
 
+// Device address of g_launch_counter on the stream's device, for the producers that carry the preparation out themselves
+// (they live in another translation unit: the address travels as a kernel argument).  One query per device and process.
+static unsigned* launch_counter_address(hipStream_t stream) {
+    static std::atomic<unsigned*> cached[64];
+    int dev = -1, cur = -2;
+    if (hipStreamGetDevice(stream, &dev) != hipSuccess || hipGetDevice(&cur) != hipSuccess) return nullptr;
+    if (dev < 0 || dev >= 64 || dev != cur) return nullptr;     // (hipGetSymbolAddress answers for the CURRENT device)
+    unsigned* p = cached[dev].load(std::memory_order_acquire);
+    if (!p) {
+        void* q = nullptr;
+        if (hipGetSymbolAddress(&q, HIP_SYMBOL(g_launch_counter)) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        p = static_cast<unsigned*>(q);
+        cached[dev].store(p, std::memory_order_release);
+    }
+    return p;
+}
+
 size_t wd_mail_bytes(int N, int T, int U) {
     const int nA = (U + WAVE - 1) / WAVE;
     // (by SHAPE only -- the larger of the two block sizes' rings: a workspace's size must not depend on a setting)
@@ -129,8 +154,27 @@ size_t wd_mail_bytes(int N, int T, int U) {
     return bytes;
 }
 
-// Needs a.redo, a.queue = a.redo + 2N with the launch counter behind it (and a.mail of wd_mail_bytes when U > 64);
-// zeroes redo, the queue head and the rings itself.  With a.redo == nullptr and U <= 64 it is a plain launch.  Sweeps it
+// bytes of rings a launch on `a` uses (by the block size it will run with)
+static size_t wd_ring_bytes(const LatticeArgs& a, int N) {
+    const int nA = (a.U + WAVE - 1) / WAVE;
+    const size_t pitch = wd_block_diagonals(a.T) == 16 ? wd16::ring_pitch(a.T, a.U) : wd8::ring_pitch(a.T, a.U);
+    return nA < 2 ? 0 : (size_t)2 * N * (nA - 1) * pitch * sizeof(wd8::u64);
+}
+
+bool wd_ring_prep(hipStream_t stream, const LatticeArgs& a, int N, RingPrep* prep) {
+    if (N <= 0 || !a.redo || !a.queue || a.queue != a.redo + 4 * N) return false;
+    const int nA = (a.U + WAVE - 1) / WAVE;
+    if (nA > 1 && !a.mail) return false;
+    unsigned* counter = launch_counter_address(stream);
+    if (!counter) return false;
+    const size_t ring_bytes = wd_ring_bytes(a, N);
+    *prep = RingPrep{a.redo, 4 * N + 1, counter, reinterpret_cast<uint4*>(a.mail), ring_bytes / 16};
+    return true;
+}
+
+// Needs a.redo -- (4N + 2) words: 2N flags, 2N counters of finished column blocks, the queue head, the launch counter's
+// value --, a.queue = a.redo + 4N (and a.mail of wd_mail_bytes when U > 64); zeroes flags, counters, queue head and rings
+// itself unless a.prepared.  With a.redo == nullptr and U <= 64 it is a plain launch.  Sweeps it
 // flags in a.redo (a lost hand-over: never observed outside the short-spin build) are for the caller to redo with the
 // single-workgroup kernel.
 hipError_t launch_lattice_wd(hipStream_t stream, const LatticeArgs& a0, int N) {
@@ -153,10 +197,10 @@ hipError_t launch_lattice_wd(hipStream_t stream, const LatticeArgs& a0, int N) {
         a.mail = nullptr;
     } else {
         a.epoch = next_launch_epoch();
-        const size_t pitch = k16 ? wd16::ring_pitch(a.T, a.U) : wd8::ring_pitch(a.T, a.U);
-        const size_t ring_bytes = nA < 2 ? 0 : (size_t)2 * N * (nA - 1) * pitch * sizeof(wd8::u64);
-        const hipError_t e = launch_ring_prepare(stream, a.redo, 2 * N + 1, a.mail, ring_bytes);
-        if (e != hipSuccess) return e;
+        if (!a.prepared) {     // (prepared: the producer of this call's pair plane did it at the tail of its own launch)
+            const hipError_t e = launch_ring_prepare(stream, a.redo, 4 * N + 1, a.mail, wd_ring_bytes(a, N));
+            if (e != hipSuccess) return e;
+        }
     }
     const dim3 grid(2 * N * nA), block(3 * WAVE);
     if (k16) {

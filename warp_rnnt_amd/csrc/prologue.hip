@@ -1275,10 +1275,26 @@ constexpr int TD = 32;   // tile edge
 #endif
 constexpr int TT = RNNT_GATHER_TT;   // frames per tile of k_to_diagonal (columns: TD)
 
+// The preparation of the ring kernel that follows in the same call (kernels.h: RingPrep; lattice_wd.hip: k_prepare is the
+// stand-alone form), carried out at the tail of a producer's workgroups: every workgroup zeroes its slice of the rings,
+// the first one clears the flags and the queue head and takes the next value of the device's launch counter.  Everything
+// is complete when the producer's launch is, i.e. before the ring kernel starts.
+__device__ __forceinline__ void fold_ring_prepare(const RingPrep& p) {
+    const size_t per = (p.ring_vec + gridDim.x - 1) / gridDim.x;
+    const size_t lo = (size_t)blockIdx.x * per;
+    const size_t hi = lo + per < p.ring_vec ? lo + per : p.ring_vec;
+    const uint4 z = make_uint4(0, 0, 0, 0);
+    for (size_t i = lo + threadIdx.x; i < hi; i += blockDim.x) p.rings[i] = z;
+    if (blockIdx.x == 0) {
+        for (int i = threadIdx.x; i < p.n_flags; i += blockDim.x) p.flags[i] = 0;
+        if (threadIdx.x == 0) p.flags[p.n_flags] = (int)(atomicAdd(p.counter, 1u) + 1u);
+    }
+}
+
 template <bool DENSE, int TTK>
 __global__ void __launch_bounds__(256)
 k_to_diagonal(const float* __restrict__ src, const int* __restrict__ labels, float2* __restrict__ ws2,
-              int T, int U, int V, int blank, int tiles_t, int tiles_u) {
+              int T, int U, int V, int blank, int tiles_t, int tiles_u, const RingPrep prep) {
     __shared__ float2 tile[TTK][TD];
     unsigned b = (DENSE && RNNT_GATHER_REVERSE) ? gridDim.x - 1 - blockIdx.x : blockIdx.x;
     const int tu = b % tiles_u; b /= tiles_u;
@@ -1323,6 +1339,7 @@ k_to_diagonal(const float* __restrict__ src, const int* __restrict__ labels, flo
             }
         }
     }
+    if (prep.flags) fold_ring_prepare(prep);
 }
 
 // Row-major (N,T,U,2) gather (what the reference's wrapper builds): one thread per cell.
@@ -1338,21 +1355,22 @@ k_gather_rowmajor(const float* __restrict__ lp, const int* __restrict__ labels, 
 
 template <int TTK>
 static hipError_t launch_to_diagonal_tt(hipStream_t stream, const float* src, const int* labels, float* ws2,
-                                        int N, int T, int U, int V, int blank, bool dense) {
+                                        int N, int T, int U, int V, int blank, bool dense, const RingPrep& prep) {
     const int tiles_t = (T + TTK - 1) / TTK, tiles_u = (U + TD - 1) / TD;
     const size_t nblk = (size_t)N * tiles_t * tiles_u;
     if (nblk >= ((size_t)1 << 31)) return hipErrorInvalidValue;
     if (dense)
         k_to_diagonal<true, TTK><<<(unsigned)nblk, 256, 0, stream>>>(src, labels, reinterpret_cast<float2*>(ws2), T, U,
-                                                                     V, blank, tiles_t, tiles_u);
+                                                                     V, blank, tiles_t, tiles_u, prep);
     else
         k_to_diagonal<false, TTK><<<(unsigned)nblk, 256, 0, stream>>>(src, labels, reinterpret_cast<float2*>(ws2), T, U,
-                                                                      2, 0, tiles_t, tiles_u);
+                                                                      2, 0, tiles_t, tiles_u, prep);
     return hipGetLastError();
 }
 
 static hipError_t launch_to_diagonal(hipStream_t stream, const float* src, const int* labels, float* ws2,
-                                     int N, int T, int U, int V, int blank, bool dense) {
+                                     int N, int T, int U, int V, int blank, bool dense, const RingPrep* prep_in) {
+    const RingPrep prep = prep_in ? *prep_in : RingPrep{nullptr, 0, nullptr, nullptr, 0};
     if ((size_t)N * T * U == 0) return hipSuccess;
     // Small problems: 32-frame tiles do not even give every CU one workgroup (c2: 94 tiles for 256 CUs); 8-frame tiles --
     // one cell per thread -- quadruple the workgroups (RNNT_GATHER_SMALL_TILES=0 / 1 forces one or the other, for A/B runs)
@@ -1360,8 +1378,8 @@ static hipError_t launch_to_diagonal(hipStream_t stream, const float* src, const
     const size_t tiles32 = (size_t)N * ((T + TT - 1) / TT) * ((U + TD - 1) / TD);
     // (dense entry, us per call, 32- / 8-frame tiles: c2 28.1 / 27.4, N=32 35.1 / 33.2, N=64 46.2 / 45.2, N=128 67.1 / 68.1)
     const bool small_tiles = force >= 0 ? force != 0 : tiles32 < 512;
-    if (small_tiles) return launch_to_diagonal_tt<8>(stream, src, labels, ws2, N, T, U, V, blank, dense);
-    return launch_to_diagonal_tt<TT>(stream, src, labels, ws2, N, T, U, V, blank, dense);
+    if (small_tiles) return launch_to_diagonal_tt<8>(stream, src, labels, ws2, N, T, U, V, blank, dense, prep);
+    return launch_to_diagonal_tt<TT>(stream, src, labels, ws2, N, T, U, V, blank, dense, prep);
 }
 
 // (Round 5 tried the dense gather as a coalesced STREAM for V <= 64, where the two dwords per row touch nearly every
@@ -1369,17 +1387,18 @@ static hipError_t launch_to_diagonal(hipStream_t stream, const float* src, const
 //  Bit-identical, and slower: c4 274 us against 250 for k_to_diagonal in the same runs, loss path 0.403 vs 0.384 ms
 //  -- a stream pays for all 1.44 GB, the scattered requests for the ~0.9 of the lines they touch.)
 hipError_t launch_gather(hipStream_t stream, const float* log_probs, const int* labels, float* out2,
-                         int N, int T, int U, int V, int blank, bool skewed) {
+                         int N, int T, int U, int V, int blank, bool skewed, const RingPrep* prep) {
     const size_t cells = (size_t)N * T * U;
     if (cells == 0) return hipSuccess;
-    if (skewed) return launch_to_diagonal(stream, log_probs, labels, out2, N, T, U, V, blank, true);
+    if (skewed) return launch_to_diagonal(stream, log_probs, labels, out2, N, T, U, V, blank, true, prep);
     k_gather_rowmajor<<<(unsigned)((cells + 255) / 256), 256, 0, stream>>>(
         log_probs, labels, reinterpret_cast<float2*>(out2), cells, T, U, V, blank);
     return hipGetLastError();
 }
 
-hipError_t launch_reskew(hipStream_t stream, const float* lp2_rowmajor, float* ws2, int N, int T, int U) {
-    return launch_to_diagonal(stream, lp2_rowmajor, nullptr, ws2, N, T, U, 2, 0, false);
+hipError_t launch_reskew(hipStream_t stream, const float* lp2_rowmajor, float* ws2, int N, int T, int U,
+                         const RingPrep* prep) {
+    return launch_to_diagonal(stream, lp2_rowmajor, nullptr, ws2, N, T, U, 2, 0, false, prep);
 }
 
 // The way back: diagonal-major pairs -> row-major (N,T,U,2), the same 32x32 tiles walked the other way round (read by
