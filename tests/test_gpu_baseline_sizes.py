@@ -178,6 +178,7 @@ def three_way(name, costs, gpairs, lp2_f32, lp2_f64, xn, yn, lam, fp64_utts=None
     if abs_bar is not None:
         assert row["grad_hip_vs_oracle"]["max"] <= abs_bar, row
     assert_close_to_the_oracle(row, gpairs, ref, xn, yn, T)
+    record(row)          # (again: now with the ulp report in it)
     # path-occupancy invariants (exact in exact arithmetic), to the accuracy just established
     # (gradient errors are relative errors of exp(.), so a row/column sum is off by about as much as its
     # largest entry)

@@ -11,6 +11,9 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from _ab import use_ab_build  # noqa: E402
+use_ab_build()      # (the build that reads the A/B knobs from the environment: tools/_ab.py)
 SHAPES = [(32, 250, 100, 128), (32, 500, 50, 128), (32, 500, 100, 128), (32, 500, 200, 128), (32, 1000, 100, 128),
           (64, 500, 100, 128), (64, 1000, 200, 128), (32, 500, 100, 1024), (16, 1500, 300, 50)]
 

@@ -12,6 +12,9 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from _ab import use_ab_build  # noqa: E402
+use_ab_build()      # (the build that reads the A/B knobs from the environment: tools/_ab.py)
 SHAPES = [(16, 150, 40, 28), (32, 150, 40, 28), (64, 150, 40, 28), (128, 150, 40, 28), (256, 150, 40, 28),
           (4, 500, 100, 50), (8, 500, 100, 50), (16, 500, 100, 50), (32, 500, 100, 50), (2, 150, 20, 5000), (8, 150, 20, 5000)]
 

@@ -15,6 +15,9 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from _ab import use_ab_build  # noqa: E402
+use_ab_build()      # (the build that reads the A/B knobs from the environment: tools/_ab.py)
 
 
 def timed(torch, fn):

@@ -3,6 +3,9 @@
 launch over the median launch time (HIP events around 10 back-to-back launches, 5 rounds), after 30 ms of load."""
 import sys, os, statistics
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from _ab import use_ab_build  # noqa: E402
+use_ab_build()      # (the build that reads the A/B knobs from the environment: tools/_ab.py)
 import torch
 from warp_rnnt_amd import ops
 

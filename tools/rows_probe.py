@@ -4,6 +4,9 @@ checks them against torch. Usage: rows_probe.py N T U V    (RNNT_LSM_NO_SHIFT=1 
 import os, statistics, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from _ab import use_ab_build  # noqa: E402
+use_ab_build()      # (the build that reads the A/B knobs from the environment: tools/_ab.py)
 import torch
 from warp_rnnt_amd import ops
 

@@ -58,7 +58,10 @@ static unsigned grid_of(int order, int N, int tiles_t, int tiles_u) {
 
 // The shipped kernel's structure, generalised: TT frames x TD columns per tile, 256 threads, non-temporal loads,
 // HOT: stores go to a 64 KB region (same addresses for every tile), X4: 16-byte stores.
-template <int TT, int TD, int ORDER, bool HOT, bool X4>
+// PITCH: 0 = the plane's rows are U pairs apart (shipped); > 0: rows padded to a multiple of PITCH pairs (16 pairs = one
+// 128-byte line: every diagonal run of a tile then starts on a line), planes T * Upad apart;
+// -1: the tile is written as ONE contiguous chunk (tile-major: what a perfectly sequential full-line write costs)
+template <int TT, int TD, int ORDER, bool HOT, bool X4, int PITCH = 0>
 __global__ void __launch_bounds__(256)
 k_tile(const float* __restrict__ src, const int* __restrict__ labels, float2* __restrict__ ws2, int N, int T, int U, int V,
        int blank, int tiles_t, int tiles_u) {
@@ -94,6 +97,12 @@ k_tile(const float* __restrict__ src, const int* __restrict__ labels, float2* __
                     int r = t + u;
                     r = r >= T ? r % T : r;
                     size_t at = nbase + (size_t)r * U + u;
+                    if constexpr (PITCH > 0) {
+                        const int Up = (U + PITCH - 1) / PITCH * PITCH;
+                        at = (size_t)id.n * T * Up + (size_t)r * Up + u;
+                    } else if constexpr (PITCH < 0) {
+                        at = ((size_t)(id.n * tiles_t + id.tt) * tiles_u + id.tu) * (TT * TD) + (size_t)tl * TD + ul;
+                    }
                     if (HOT) at &= 8191;
                     ws2[at] = tile[tl][ul];
                 }
@@ -226,7 +235,7 @@ int main(int argc, char** argv) {
     float2 *ref, *out;
     int* labels;
     CHECK(hipMalloc(&src, bytes + 16));
-    CHECK(hipMalloc(&ref, cells * 8)); CHECK(hipMalloc(&out, cells * 8));
+    CHECK(hipMalloc(&ref, cells * 8)); CHECK(hipMalloc(&out, cells * 8 + cells * 8 / 4));
     CHECK(hipMalloc(&labels, (size_t)N * (U - 1) * 4 + 4));
     {
         std::vector<float> h(cells * V);
@@ -270,6 +279,19 @@ int main(int argc, char** argv) {
         TILE(64, 64, 2, false, false, out, true, "64 frames x 64 columns strips per XCD")
         TILE(64, 64, 2, false, true, out, true, "64 frames x 64 columns strips per XCD, 16-byte stores")
         TILE(16, 64, 0, false, false, out, true, "16 frames x 64 columns linear")
+#define TILEP(TT, TD, ORDER, PITCH, label)                                                                             \
+    {                                                                                                                 \
+        const int tiles_t = (T + TT - 1) / TT, tiles_u = (U + TD - 1) / TD;                                           \
+        const unsigned grid = grid_of(ORDER, N, tiles_t, tiles_u);                                                    \
+        run(label, [&] { k_tile<TT, TD, ORDER, false, false, PITCH><<<grid, 256>>>(src, labels, out, N, T, U, V, 0, tiles_t, tiles_u); }); \
+        CHECK(hipMemset(out, 0xff, cells * 8));                                                                       \
+    }
+        TILEP(32, 32, 1, 16, "32x32 reversed, rows padded to whole 128-byte lines (U 300 -> 304)")
+        TILEP(32, 32, 1, 32, "32x32 reversed, rows padded to 256 bytes (U 300 -> 320)")
+        TILEP(32, 64, 1, 16, "32 frames x 64 columns reversed, rows padded to whole lines")
+        TILEP(32, 32, 1, -1, "32x32 reversed, tile written as one contiguous 8 KB chunk (tile-major)")
+        TILEP(32, 32, 0, 16, "32x32 forward, rows padded to whole 128-byte lines")
+        TILEP(16, 32, 1, 16, "16x32 reversed, rows padded to whole lines")
         TILE(16, 128, 0, false, false, out, true, "16 frames x 128 columns linear")
         {
             const int tiles_t = (T + 31) / 32, tiles_u = (U + 31) / 32;

@@ -66,8 +66,9 @@ VARIANTS = {
     # A/B of k_lattice_wl's wave placement: six waves in column-block-major order / compute waves at raised priority
     "wl_nopad": ["-DRNNT_WL_PAD=0"],
     "wl_noprio": ["-DRNNT_WL_PRIO=0"],
-    # A/B of the in-kernel redo (round 6): the redo kernel launched behind k_lattice_wd on every call, as in rounds 4-5
-    "redo_launch": ["-DRNNT_WD_INKERNEL_REDO=0"],
+    # the build that reads the kernel-selection knobs of DESIGN.md section 10 from the environment (common.h: ab_getenv); the
+    # probes under tools/ load it through WARP_RNNT_AMD_LIB -- the shipped library ignores those variables
+    "ab": ["-DRNNT_AB_KNOBS"],
     # a build that MUST FAIL: the hand-written blocks end with two of their in-place reloads still in flight -- the bug
     # class of round 5; tests/test_host_cpu.py checks that build() refuses it (warp_rnnt_amd/_isa_check.py)
     "planted_violation": ["-DRNNT_PLANT_RELOAD_VIOLATION"],

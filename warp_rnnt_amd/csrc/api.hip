@@ -25,7 +25,7 @@ inline size_t align_up(size_t x) { return (x + ALIGN - 1) / ALIGN * ALIGN; }
 // T=500, U=100, V=50: N=4 ... 32 (0.2 M ... 1.6 M cells) equal within 0.5 us.  RNNT_DENSE_ONE_LAUNCH_CELLS overrides
 // (0: never), for A/B runs.
 inline size_t dense_in_one_launch_cells() {
-    static const size_t v = getenv("RNNT_DENSE_ONE_LAUNCH_CELLS") ? (size_t)atoll(getenv("RNNT_DENSE_ONE_LAUNCH_CELLS"))
+    static const size_t v = ab_getenv("RNNT_DENSE_ONE_LAUNCH_CELLS") ? (size_t)atoll(ab_getenv("RNNT_DENSE_ONE_LAUNCH_CELLS"))
                                                                   : ((size_t)1 << 20);
     return v;
 }
@@ -36,7 +36,7 @@ struct Workspace {
     float* ws2;      // diagonal-major (blank,label) pairs; later the gathered grads
     float* ll;
     int* mismatch;
-    int* redo;       // (4N + 2,) flags and done counters of k_lattice_wd, the work-item counter, the launch counter's value
+    int* redo;       // (2N + 2,) redo flags of k_lattice_wd, its work-item counter, the launch counter's value
     unsigned long long* mail;   // boundary-column rings of k_lattice_wd (kernels.h)
 };
 
@@ -50,7 +50,7 @@ size_t carve(void* base, int N, int T, int U, Workspace* w) {
     float* ws2 = reinterpret_cast<float*>(take(cells * 2 * sizeof(float)));
     float* ll = reinterpret_cast<float*>(take((size_t)N * sizeof(float)));
     int* mismatch = reinterpret_cast<int*>(take((size_t)N * sizeof(int)));
-    int* redo = reinterpret_cast<int*>(take(((size_t)N * 4 + 2) * sizeof(int)));   // flags, done counters, queue head, launch counter
+    int* redo = reinterpret_cast<int*>(take(((size_t)N * 2 + 2) * sizeof(int)));   // flags, queue head, launch counter
     // (reserved by SHAPE, never by the current route: the size of a workspace must not depend on a setting)
     unsigned long long* mail = reinterpret_cast<unsigned long long*>(take(lattice_mail_bytes(N, T, U)));
     if (w) *w = Workspace{alphas, betas, ws2, ll, mismatch, redo, mail};
@@ -124,14 +124,14 @@ rnntStatus_t run_warp_rnnt(rnntStream_t stream, unsigned int* counts, float* alp
         size_t off = align_up(cells * 2 * sizeof(float));
         int* redo = nullptr;
         unsigned long long* mail = nullptr;
-        const size_t flag_bytes = align_up(((size_t)N * 4 + 2) * sizeof(int)), ring_bytes = lattice_mail_bytes(N, T, U);
+        const size_t flag_bytes = align_up(((size_t)N * 2 + 2) * sizeof(int)), ring_bytes = lattice_mail_bytes(N, T, U);
         if (reinterpret_cast<uintptr_t>(base) % ALIGN == 0 && off + flag_bytes + align_up(ring_bytes) <= avail) {
             redo = reinterpret_cast<int*>(base + off);
             off += flag_bytes;
             mail = reinterpret_cast<unsigned long long*>(base + off);
             off += align_up(ring_bytes);
         }
-        LatticeArgs la{grads, nullptr, xn, yn, alphas, betas, ll, T, U, 2, 0, nullptr, redo, redo ? redo + 4 * N : nullptr, mail};
+        LatticeArgs la{grads, nullptr, xn, yn, alphas, betas, ll, T, U, 2, 0, nullptr, redo, redo ? redo + 2 * N : nullptr, mail};
         RingPrep prep{nullptr, 0, nullptr, nullptr, 0};
         la.prepared = lattice_ring_prep(stream, la, N, LOAD_SKEWED, &prep) ? 1 : 0;
         if (launch_gather(stream, log_probs, labels, grads, N, T, U, V, blank, true, &prep) != hipSuccess)
@@ -220,7 +220,7 @@ rnntStatus_t rnnt_amd_loss(rnntStream_t stream, void* workspace, int input_kind,
 
     // 1. bring the (blank,label) log-prob pairs into the diagonal-major workspace -- and, where the sweeps are going to run on
     //    the ring kernel, let that launch prepare its flags and rings on the way (kernels.h: RingPrep)
-    LatticeArgs la{w.ws2, nullptr, xn, yn, w.alphas, w.betas, w.ll, T, U, 2, 0, nullptr, w.redo, w.redo + 4 * N, w.mail};
+    LatticeArgs la{w.ws2, nullptr, xn, yn, w.alphas, w.betas, w.ll, T, U, 2, 0, nullptr, w.redo, w.redo + 2 * N, w.mail};
     RingPrep prep{nullptr, 0, nullptr, nullptr, 0};
     hipError_t e;
     switch (input_kind) {
@@ -278,7 +278,7 @@ rnntStatus_t rnnt_amd_debug_lattice_only(rnntStream_t stream, void* workspace, c
     if (!dims_ok(N, T, U) || !workspace) return RNNT_STATUS_INVALID_ARGUMENT;
     Workspace w;
     carve(workspace, N, T, U, &w);
-    LatticeArgs la{w.ws2, nullptr, xn, yn, w.alphas, w.betas, w.ll, T, U, 2, 0, nullptr, w.redo, w.redo + 4 * N, w.mail};
+    LatticeArgs la{w.ws2, nullptr, xn, yn, w.alphas, w.betas, w.ll, T, U, 2, 0, nullptr, w.redo, w.redo + 2 * N, w.mail};
     if (launch_lattice(stream, la, N, LOAD_SKEWED) != hipSuccess) return RNNT_STATUS_WARP_FAILED;
     return RNNT_STATUS_SUCCESS;
 }
@@ -302,7 +302,7 @@ size_t carve_compact(void* base, int N, int64_t STU, int Tmax, int Umax, Compact
     float* ws2 = reinterpret_cast<float*>(take((size_t)STU * 8));
     float* ll = reinterpret_cast<float*>(take((size_t)N * 4));
     int* mismatch = reinterpret_cast<int*>(take((size_t)N * 4));
-    int* redo = reinterpret_cast<int*>(take(((size_t)N * 4 + 2) * sizeof(int)));
+    int* redo = reinterpret_cast<int*>(take(((size_t)N * 2 + 2) * sizeof(int)));
     unsigned long long* mail = reinterpret_cast<unsigned long long*>(take(lattice_mail_bytes(N, Tmax, Umax)));
     if (w) *w = CompactWorkspace{alphas, betas, ws2, ll, mismatch, redo, mail};
     return off + ALIGN;
@@ -359,7 +359,7 @@ rnntStatus_t rnnt_amd_loss_compact(rnntStream_t stream, void* workspace, const f
     if (launch_gather_compact(stream, xs, ys, xn, yn, cell_offsets, label_offsets, ws2, loc, N, Tmax, Umax, V,
                               blank, STU) != hipSuccess)
         return RNNT_STATUS_PROLOGUE_FAILED;
-    LatticeArgs la{ws2, nullptr, xn, yn, alphas, betas, ll, Tmax, Umax, 2, 0, cell_offsets, w.redo, w.redo + 4 * N, w.mail};
+    LatticeArgs la{ws2, nullptr, xn, yn, alphas, betas, ll, Tmax, Umax, 2, 0, cell_offsets, w.redo, w.redo + 2 * N, w.mail};
     if (launch_lattice(stream, la, N, LOAD_SKEWED) != hipSuccess) return RNNT_STATUS_WARP_FAILED;
     GradArgs ga{ws2, nullptr, xn, yn, alphas, betas, ll, grads2 ? grads2 : ws2, costs, mismatch,
                 Tmax, Umax, 2, 0, fastemit_lambda, cell_offsets};

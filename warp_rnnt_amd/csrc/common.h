@@ -4,9 +4,24 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <cstdlib>
+
 namespace rnnt {
 
 constexpr int WAVE = 64;
+
+// Kernel-selection knobs for A/B timing runs (which log-softmax cover, which tile order, ...) are read
+// from the environment ONLY in the build made for that -- -DRNNT_AB_KNOBS, the `ab` variant of warp_rnnt_amd/_build.py,
+// which the probes under tools/ load through WARP_RNNT_AMD_LIB.  The shipped library ignores them: what it does is a
+// function of the call's arguments (round 6; until then ~20 variables were read once per process by every build).
+inline const char* ab_getenv(const char* name) {
+#ifdef RNNT_AB_KNOBS
+    return getenv(name);
+#else
+    (void)name;
+    return nullptr;
+#endif
+}
 
 // ---------------------------------------------------------------------------
 // Diagonal-major ("skewed") lattice layout.

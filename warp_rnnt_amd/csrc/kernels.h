@@ -16,12 +16,10 @@ struct LatticeArgs {
     int T, U, V, blank;   // V/blank: LOAD_DENSE only
     const int64_t* offs;  // compact layout: (N+1,) cell offset of each utterance's (T_n, U_n) plane;
                           // nullptr = padded (N,T,U) planes
-    int* redo;            // (4N + 2 words with queue) [2n+dir]: set by k_lattice_wd when a hand-over between column blocks
-                          // timed out (bit 1); [2N + 2n+dir]: how many column blocks of the sweep have finished -- the last
-                          // one redoes a flagged sweep itself (lattice_wd_body.h).  The single-workgroup kernels sweep
-                          // only the flagged sweeps when given one (nothing in the library does that any more);
-                          // nullptr = the kernels that need no flags only
-    int* queue;           // work-item counter of k_lattice_wd; MUST be redo + 4N (zeroed together);
+    int* redo;            // (2N,) [2n+dir]: set by k_lattice_wd when a hand-over between column blocks timed out (bit 1),
+                          // read by the single-workgroup kernel launched behind it (0 = nothing to do); nullptr = the
+                          // kernels that need no flags only
+    int* queue;           // work-item counter of k_lattice_wd; MUST be redo + 2N (zeroed together);
                           // queue[1] is its launch counter (never zeroed: any start value will do)
     unsigned long long* mail;  // its hand-over rings between column blocks (wd_mail_bytes), needed when U > 64
     unsigned epoch;       // filled in by launch_lattice_wd
@@ -91,7 +89,6 @@ hipError_t launch_lattice_ws(hipStream_t stream, const LatticeArgs& a, int N);
 // hipErrorNotSupported when they are missing.
 hipError_t launch_lattice_wd(hipStream_t stream, const LatticeArgs& a, int N);
 size_t wd_mail_bytes(int N, int T, int U);
-bool wd_redoes_in_kernel();   // (compile-time RNNT_WD_INKERNEL_REDO: no kernel is launched behind k_lattice_wd)
 // ... and its single-workgroup form (lattice_wd.hip: k_lattice_wl): all column blocks of a sweep as waves of one
 // workgroup, boundary columns through LDS; needs nothing but the planes (no flags, no rings), padded or compact with
 // either offset width, honours a.redo and a.beta_only.  hipErrorNotSupported beyond max_blocks (<= 5) column blocks.

@@ -136,7 +136,7 @@ static bool takes_ring_kernel(hipStream_t stream, const LatticeArgs& a, int N, i
 }
 
 bool lattice_ring_prep(hipStream_t stream, const LatticeArgs& a, int N, int loader, RingPrep* prep) {
-    static const bool off = getenv("RNNT_NO_PREP_FOLD") != nullptr;     // A/B knob: k_prepare as a launch of its own
+    static const bool off = ab_getenv("RNNT_NO_PREP_FOLD") != nullptr;     // A/B knob: k_prepare as a launch of its own
     if (off || !takes_ring_kernel(stream, a, N, loader)) return false;
     return wd_ring_prep(stream, a, N, prep);
 }
@@ -151,10 +151,10 @@ hipError_t launch_lattice(hipStream_t stream, const LatticeArgs& a, int N, int l
         // (the kernel that hands boundary columns over through L2 rings needs the flags, the work queue and the rings --
         //  compact layout: the native entry's 64-bit cell offsets; a.T / a.U are then the launch bounds Tmax / Umax:
         //  takes_ring_kernel above)
-        // ... and behind it -- only in builds with RNNT_WD_INKERNEL_REDO=0 -- the single-workgroup kernel for the sweeps it
-        // flagged (normally none: its workgroups read one flag and return)
+        // ... and behind it the single-workgroup kernel for the sweeps it flagged (normally none: its workgroups read one
+        // flag and return: 5 us per call; redoing inside k_lattice_wd instead was tried in round 6 and costs more,
+        // lattice_wd_body.h)
         auto redo_behind = [&]() {
-            if (wd_redoes_in_kernel()) return hipSuccess;      // (round 6: the last column block to finish redoes)
             const hipError_t e = launch_lattice_ws(stream, a, N);
             return e != hipErrorNotSupported ? e : launch_single(stream, a, N, loader);
         };

@@ -1,8 +1,9 @@
 // The single-role lattice sweep (one workgroup per sweep, every wave computes and does its own I/O; any of the three
-// loaders; lattices wider than the workgroup in column stripes): the body of lattice.hip's k_lattice, in a header since
-// round 6 because lattice_wd.hip's k_lattice_wd calls it too -- as the in-kernel redo of a sweep whose hand-over between
-// column blocks was lost (lattice_wd_body.h).  Reference: core_gather.cu:37-133 (alphas), :135-234 (betas); the
-// arithmetic and its order are lattice_step.h's (same bits: tests/test_gpu_wd.py).  Read lattice.hip's header first.
+// loaders; lattices wider than the workgroup in column stripes): the body of lattice.hip's k_lattice.  A header since
+// round 6, when k_lattice_wd was given a copy of it as an in-kernel redo of sweeps with a lost hand-over (measured
+// slower than the idle redo launch it replaced, and removed again: lattice_wd_body.h); lattice.hip is its one user.
+// Reference: core_gather.cu:37-133 (alphas), :135-234 (betas); the arithmetic and its order are lattice_step.h's (same
+// bits: tests/test_gpu_wd.py).  Read lattice.hip's header first.
 #pragma once
 #include <type_traits>
 

@@ -50,17 +50,9 @@
 
 #include "common.h"
 #include "kernels.h"
-#include "lattice_single.h"
 #include "lattice_step.h"
 
 namespace rnnt {
-
-// 1: a sweep flagged by a lost hand-over is redone INSIDE k_lattice_wd by the last of its workgroups to finish
-// (lattice_wd_body.h); 0: by a kernel launched behind it on every call (rounds 4-5: k_lattice_ws, idle 5 us per step)
-#ifndef RNNT_WD_INKERNEL_REDO
-#define RNNT_WD_INKERNEL_REDO 1
-#endif
-bool wd_redoes_in_kernel() { return RNNT_WD_INKERNEL_REDO != 0; }
 
 #define RNNT_WD_NS wd8
 #define RNNT_WD_KK 8
@@ -162,19 +154,18 @@ static size_t wd_ring_bytes(const LatticeArgs& a, int N) {
 }
 
 bool wd_ring_prep(hipStream_t stream, const LatticeArgs& a, int N, RingPrep* prep) {
-    if (N <= 0 || !a.redo || !a.queue || a.queue != a.redo + 4 * N) return false;
+    if (N <= 0 || !a.redo || !a.queue || a.queue != a.redo + 2 * N) return false;
     const int nA = (a.U + WAVE - 1) / WAVE;
     if (nA > 1 && !a.mail) return false;
     unsigned* counter = launch_counter_address(stream);
     if (!counter) return false;
     const size_t ring_bytes = wd_ring_bytes(a, N);
-    *prep = RingPrep{a.redo, 4 * N + 1, counter, reinterpret_cast<uint4*>(a.mail), ring_bytes / 16};
+    *prep = RingPrep{a.redo, 2 * N + 1, counter, reinterpret_cast<uint4*>(a.mail), ring_bytes / 16};
     return true;
 }
 
-// Needs a.redo -- (4N + 2) words: 2N flags, 2N counters of finished column blocks, the queue head, the launch counter's
-// value --, a.queue = a.redo + 4N (and a.mail of wd_mail_bytes when U > 64); zeroes flags, counters, queue head and rings
-// itself unless a.prepared.  With a.redo == nullptr and U <= 64 it is a plain launch.  Sweeps it
+// Needs a.redo, a.queue = a.redo + 2N with the launch counter's value behind it (and a.mail of wd_mail_bytes when U > 64);
+// zeroes flags, queue head and rings itself unless a.prepared.  With a.redo == nullptr and U <= 64 it is a plain launch.  Sweeps it
 // flags in a.redo (a lost hand-over: never observed outside the short-spin build) are for the caller to redo with the
 // single-workgroup kernel.
 hipError_t launch_lattice_wd(hipStream_t stream, const LatticeArgs& a0, int N) {
@@ -198,7 +189,7 @@ hipError_t launch_lattice_wd(hipStream_t stream, const LatticeArgs& a0, int N) {
     } else {
         a.epoch = next_launch_epoch();
         if (!a.prepared) {     // (prepared: the producer of this call's pair plane did it at the tail of its own launch)
-            const hipError_t e = launch_ring_prepare(stream, a.redo, 4 * N + 1, a.mail, wd_ring_bytes(a, N));
+            const hipError_t e = launch_ring_prepare(stream, a.redo, 2 * N + 1, a.mail, wd_ring_bytes(a, N));
             if (e != hipSuccess) return e;
         }
     }
@@ -221,7 +212,7 @@ int wl_max_blocks() {
     // the CU's 160 (LDS-DMA lands above 64 KiB as well: M0 carries the full address on gfx950 -- tests/test_gpu_wd.py).
     // RNNT_WL_MAX_BLOCKS = 0 ... 5 overrides (0: the kernel is never chosen), for A/B runs.
     static const int v = [] {
-        const char* e = getenv("RNNT_WL_MAX_BLOCKS");
+        const char* e = ab_getenv("RNNT_WL_MAX_BLOCKS");
         const int d = e ? atoi(e) : RNNT_WL_DEFAULT_MAX_BLOCKS;
         return d < 0 ? 0 : (d > 5 ? 5 : d);
     }();

@@ -472,28 +472,10 @@ __device__ __forceinline__ void sweep(const LatticeArgs& a, const Item it, const
     }
 }
 
-#if RNNT_WD_INKERNEL_REDO
-// The redo of a flagged sweep by the workgroup that finished it last: the single-role sweep of lattice_single.h with this
-// workgroup's three waves (column stripes of 192).  Inlined -- as a real call the kernel does not compile (the inline
-// assembly's scalar operands stop being provably uniform: "illegal VGPR to SGPR copy") -- at the very end of the kernel,
-// behind everything that is ever executed in a launch without a lost hand-over.  Its mailbox lives in the column block's
-// own LDS, which is dead by then.
-template <bool COMPACT>
-__device__ __forceinline__ void redo_sweep(const LatticeArgs& a0, const int n, const int dir, Smem& sm) {
-    static_assert(sizeof(sm.pairs) >= sizeof(float) * single::MAXW * (single::RING + single::MAIL_TRASH), "redo mailbox fits");
-    float (*redo_mail)[single::RING] = reinterpret_cast<float (*)[single::RING]>(&sm.pairs[0][0][0]);
-    float (*redo_trash)[single::MAIL_TRASH] = reinterpret_cast<float (*)[single::MAIL_TRASH]>(redo_mail + single::MAXW);
-    LatticeArgs a = a0;
-    a.redo = nullptr;
-    if (dir) single::sweep<LOAD_SKEWED, true, COMPACT>(a, n, redo_mail, redo_trash);
-    else single::sweep<LOAD_SKEWED, false, COMPACT>(a, n, redo_mail, redo_trash);
-}
-#endif
-
 template <bool COMPACT>
 __global__ void __launch_bounds__(3 * WAVE) k_lattice_wd(LatticeArgs a, const int nA) {
     __shared__ Smem sm;
-    __shared__ int wg_bad, s_item, s_redo;
+    __shared__ int wg_bad, s_item;
     // launch epoch = host counter (constant across the replays of a captured graph) + the library's per-device launch
     // counter (queue[1], bumped by the preparation kernel in front of every launch, replayed or not)
     // (a.queue == nullptr: the launch of single-column-block lattices -- nothing is handed over, so there is no work
@@ -524,27 +506,12 @@ __global__ void __launch_bounds__(3 * WAVE) k_lattice_wd(LatticeArgs a, const in
 #undef RNNT_WD_SWEEP
     }
     __syncthreads();
-#if RNNT_WD_INKERNEL_REDO
-    // A lost hand-over (a wait that timed out: never observed outside the short-spin test build) leaves the sweep's planes
-    // wrong from that column block on.  Until round 5 a second kernel was launched behind this one on every call to redo
-    // flagged sweeps -- idle 5 us, every step.  Now the LAST workgroup of a sweep to finish looks at the sweep's flag and,
-    // if it is set, sweeps the whole lattice again by itself (lattice_single.h: the single-role sweep, three waves, column
-    // stripes of 192; same arithmetic, same bits).  Every workgroup releases its plane stores (agent scope: they are
-    // written back from its XCD's L2) before it counts itself done, so nothing of the abandoned attempt can land on top
-    // of the redo.  No ring launch without the counters: a.queue != nullptr.
-    if (a.queue) {
-        if (threadIdx.x == 0) {
-            const int sweep = 2 * it.n + it.dir;
-            if (wg_bad) atomicOr(&a.redo[sweep], wg_bad);
-            const int finished = __hip_atomic_fetch_add(&a.redo[sweeps + sweep], 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-            s_redo = finished == nA - 1 ? __hip_atomic_load(&a.redo[sweep], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
-        }
-        __syncthreads();
-        if (s_redo) redo_sweep<COMPACT>(a, it.n, it.dir, sm);
-    }
-#else
+    // (Round 6 tried to redo a flagged sweep HERE, by the last of the sweep's workgroups to finish, instead of by a kernel
+    //  launched behind this one on every call: every workgroup then has to release its plane stores at agent scope before
+    //  it counts itself done -- a write-back of its XCD's L2 -- and that costs more than the idle launch it saves: alpha+beta
+    //  alone 105.0 vs 101.8 us at N=16, T=1500, U=300 and 80.3 vs 74.0 at N=32, T=1000, U=200 with the 5 us launch counted
+    //  on the other side; profiles/r06_lattice_helpers_ab.txt.  Removed.)
     if (threadIdx.x == 0 && wg_bad && a.redo) atomicOr(&a.redo[2 * it.n + it.dir], wg_bad);
-#endif
 }
 
 // ---------------------------------------------------------------------------------------------------------------

@@ -843,7 +843,7 @@ static hipError_t dispatch_lsm(hipStream_t stream, const float* x, float* out, c
                          (GATHER || reinterpret_cast<uintptr_t>(out) % 16 == 0);
     if constexpr (MODE == LSM_NORM) {
         // rows in registers where the vocabulary allows it (RNNT_LSM_NO_REGS=1: the LDS-staged kernel, for A/B runs)
-        static const bool no_regs = getenv("RNNT_LSM_NO_REGS") != nullptr;
+        static const bool no_regs = ab_getenv("RNNT_LSM_NO_REGS") != nullptr;
         // (below V = 32 -- four rows per group -- the LDS-staged kernel with its straight-line row pass is the faster one
         //  since round 4: the c4 lattice with V=24 0.584 -> 0.536 ms per step, V=28 0.589-0.605 -> 0.584, c2 0.0343 -> 0.0336;
         //  from V = 32 on this kernel wins inside the step: V=40 0.71 vs 0.73, V=50 0.870 vs 0.893; tools/step_rate.py)
@@ -856,7 +856,7 @@ static hipError_t dispatch_lsm(hipStream_t stream, const float* x, float* out, c
             // scalar instructions): V=50 1.44 GB equal, 5.76 GB 5.66 -> 5.86 TB/s, V=64 6.25 -> 6.40, 100 5.92 -> 6.19, 128
             // 6.15 -> 6.44; the c4 step in bench.py 0.8759 / 0.8781 / 0.8779 -> 0.8726 / 0.8702 / 0.8709 ms, three
             // interleaved pairs (profiles/r04_lsm_xcd_order_ab.txt).  RNNT_LSM_REGS_XCD=0: the plain order (A/B runs)
-            static const int regs_xcd = getenv("RNNT_LSM_REGS_XCD") ? atoi(getenv("RNNT_LSM_REGS_XCD")) : 1;
+            static const int regs_xcd = ab_getenv("RNNT_LSM_REGS_XCD") ? atoi(ab_getenv("RNNT_LSM_REGS_XCD")) : 1;
             if (regs_xcd) grid = (grid + 7) / 8 * 8;
             if (grid < ((int64_t)1 << 31)) {
 #define LSM_REGS(KR) \
@@ -877,7 +877,7 @@ static hipError_t dispatch_lsm(hipStream_t stream, const float* x, float* out, c
         // V=256 5.82 -> 6.44, 496 5.33 -> 6.12, 500 5.14 -> 5.90, 512 5.77 -> 6.47, 768 5.58 -> 6.15, 980 5.26 -> 6.00,
         // 1000 5.14 -> 6.10, 1024 5.76 -> 6.59; with 94 % of the lanes busy still +4 ... +10 % (484, 724, 964), below
         // that -- and below 98 % for a single wave (V=244: 5.53 -> 5.23) -- the tiles win (V=200, 400, 600: 78 / 59 %).
-        static const bool no_lgr = getenv("RNNT_LSM_NO_LGR") != nullptr;    // A/B runs: the LDS-staged kernel instead
+        static const bool no_lgr = ab_getenv("RNNT_LSM_NO_LGR") != nullptr;    // A/B runs: the LDS-staged kernel instead
         if (aligned && !no_lgr && V % 4 == 0 && V > 128 && V <= 1024) {
             const int nvec = V >> 2, th = (nvec + 63) / 64 * 64;
             const unsigned grid = (unsigned)(rows < (1 << 22) ? rows : (1 << 22));
@@ -911,9 +911,9 @@ static hipError_t dispatch_lsm(hipStream_t stream, const float* x, float* out, c
         // to 256, and every V % 4 == 0 from 448 on.
         // (RNNT_LSM_NO_ROWS=1: the LDS-staged kernel, for A/B runs; RNNT_LSM_NO_DIAG=1: consecutive rows per wave for
         //  every V; RNNT_LSM_ROWS_ANY=1: this kernel for every V % 4 == 0)
-        static const bool no_rows = getenv("RNNT_LSM_NO_ROWS") != nullptr;
-        static const bool no_diag = getenv("RNNT_LSM_NO_DIAG") != nullptr;
-        static const bool rows_any = getenv("RNNT_LSM_ROWS_ANY") != nullptr;
+        static const bool no_rows = ab_getenv("RNNT_LSM_NO_ROWS") != nullptr;
+        static const bool no_diag = ab_getenv("RNNT_LSM_NO_DIAG") != nullptr;
+        static const bool rows_any = ab_getenv("RNNT_LSM_ROWS_ANY") != nullptr;
         const bool rows_rule = V == 32 || V == 64 || V == 128 || V == 256 || V >= 448;
         if (aligned && !no_rows && V % 4 == 0 && V >= 32 && V <= 1024 && (rows_rule || rows_any)) {
             int L = 8;
@@ -943,23 +943,23 @@ static hipError_t dispatch_lsm(hipStream_t stream, const float* x, float* out, c
         int L = 1;
         while (L < 64 && L * 16 < V) L <<= 1;          // <= 16 columns per lane
 #ifdef RNNT_LG_PROBE
-        if (const char* e = getenv("RNNT_LSM_L")) { const int l = atoi(e); if (l >= 1 && l <= 64 && (l & (l - 1)) == 0) L = l; }
+        if (const char* e = ab_getenv("RNNT_LSM_L")) { const int l = atoi(e); if (l >= 1 && l <= 64 && (l & (l - 1)) == 0) L = l; }
 #endif
         const int q = (V + L - 1) / L;
         const int rpp = SM_THREADS / L;                // rows per pass, a multiple of 4
         int R = (SM_FLOATS / V) / rpp * rpp;           // whole passes
         if (R < rpp) R = rpp;
         // wave-private tiles: each wave owns WAVE/L rows (a multiple of 4 for L <= 16), one pass
-        static const bool no_wp = getenv("RNNT_LSM_NO_WP") != nullptr;
+        static const bool no_wp = ab_getenv("RNNT_LSM_NO_WP") != nullptr;
         // Plain log-softmax only: measured 2-3 % faster there (0.506 -> 0.493 ms at c4), slower for the fused
         // gather (its one-lane-per-row mapping phase wants all rows of the tile in ONE wave: 0.52 -> 0.556 ms)
         // and for the fused backward (+15 us).
-        static const bool wp_fused = getenv("RNNT_LSM_WP_FUSED") != nullptr;      // (A/B: the wave-private form in the fused modes)
+        static const bool wp_fused = ab_getenv("RNNT_LSM_WP_FUSED") != nullptr;      // (A/B: the wave-private form in the fused modes)
         const bool wp = (L <= 16) && !no_wp && (MODE == LSM_NORM || wp_fused);
         if (wp) R = rpp;
         size_t lds = (size_t)R * V * sizeof(float) + (GATHER ? (size_t)R * sizeof(float2) : 0);
 #ifdef RNNT_LG_PROBE      // probe: fewer resident workgroups per CU (LDS the kernel does not use)
-        if (const char* e = getenv("RNNT_LSM_LDS")) { const size_t want = (size_t)atoi(e); if (want > lds && want <= 65536) lds = want; }
+        if (const char* e = ab_getenv("RNNT_LSM_LDS")) { const size_t want = (size_t)atoi(e); if (want > lds && want <= 65536) lds = want; }
 #endif
         const unsigned grid = stream_grid<XCD_LSM_SMALL>((unsigned)((rows + R - 1) / R));
 #define LSM_SMALL(LL)                                                                           \
@@ -984,10 +984,10 @@ static hipError_t dispatch_lsm(hipStream_t stream, const float* x, float* out, c
         // 6.0-6.5 [5.7 / 6.1], 7168 6.2 / 6.4, 8192 6.0-6.2 / 6.3-6.4 [5.8 / 6.2], 16384 5.2-5.4 / 6.0 [5.3 / 6.2];
         // nothing at 2048, 4096, 5120 ... 6144, 12288; WORSE for the three-pass covers of 2048 < V/4 <= 3072 (V=10000:
         // 6.0 / 5.6 [5.9 / 5.6]), which keep the plain order.  RNNT_LG_XCD=0 / 1 forces one or the other (A/B runs).
-        static const int xcd_force = getenv("RNNT_LG_XCD") ? atoi(getenv("RNNT_LG_XCD")) : -1;
+        static const int xcd_force = ab_getenv("RNNT_LG_XCD") ? atoi(ab_getenv("RNNT_LG_XCD")) : -1;
         // (fused gather / backward modes: no difference at c3 -- fused forward 0.3196 / 0.3184 / 0.3181 vs 0.3186 / 0.3178 /
         //  0.3190 ms -- so they keep the plain order; RNNT_LG_XCD_FUSED=1 to try)
-        static const int xcd_fused = getenv("RNNT_LG_XCD_FUSED") ? atoi(getenv("RNNT_LG_XCD_FUSED")) : 0;
+        static const int xcd_fused = ab_getenv("RNNT_LG_XCD_FUSED") ? atoi(ab_getenv("RNNT_LG_XCD_FUSED")) : 0;
         if constexpr (MODE == LSM_NORM) {
             const int nv4 = V >> 2;
             bw.xcd = xcd_force >= 0 ? (xcd_force != 0) : !(nv4 > 2048 && nv4 <= 3072);
@@ -997,7 +997,7 @@ static hipError_t dispatch_lsm(hipStream_t stream, const float* x, float* out, c
         unsigned grid = (unsigned)(rows < (1 << 22) ? rows : (1 << 22));
         if (bw.xcd) grid = (grid + 7u) & ~7u;
 #ifdef RNNT_LG_PROBE
-        if (const char* e = getenv("RNNT_LG_VARIANT")) {
+        if (const char* e = ab_getenv("RNNT_LG_VARIANT")) {
             int th = 0, nv = 0;
             sscanf(e, "%d,%d", &th, &nv);
 #define LGV(TH, NV) if (th == TH && nv == NV && V <= TH * 4 * NV) { k_lsm_large<MODE, TH, NV><<<grid, TH, 0, stream>>>(x, out, labels, rows, V, T, U, blank, bw); return hipGetLastError(); }
@@ -1221,10 +1221,10 @@ hipError_t launch_log_softmax_backward(hipStream_t stream, const float* dy, cons
         // every XCD streams a contiguous eighth of the rows (as the forward kernel, dispatch_lsm): the reference's call
         // chain with the native log-softmax function at c3 2.08 / 2.07 / 2.03 -> 2.03 / 2.03 / 1.99 ms per training step;
         // RNNT_LSMBWD_XCD=0: the plain order (A/B runs)
-        static const int bxcd = getenv("RNNT_LSMBWD_XCD") ? atoi(getenv("RNNT_LSMBWD_XCD")) : 1;
+        static const int bxcd = ab_getenv("RNNT_LSMBWD_XCD") ? atoi(ab_getenv("RNNT_LSMBWD_XCD")) : 1;
         unsigned grid = (unsigned)(rows < (1 << 22) ? rows : (1 << 22));
         if (bxcd) grid = (grid + 7u) & ~7u;
-        static const bool old_rule = getenv("RNNT_LSMBWD_SMALLEST_COVER") != nullptr;    // (A/B knob)
+        static const bool old_rule = ab_getenv("RNNT_LSMBWD_SMALLEST_COVER") != nullptr;    // (A/B knob)
         if (old_rule) {
             if (V <= 4096) k_lsmbwd_large<256, 4><<<grid, 256, 0, stream>>>(dy, y, dx, rows, V, bxcd);
             else if (V <= 8192) k_lsmbwd_large<256, 8><<<grid, 256, 0, stream>>>(dy, y, dx, rows, V, bxcd);
@@ -1374,7 +1374,7 @@ static hipError_t launch_to_diagonal(hipStream_t stream, const float* src, const
     if ((size_t)N * T * U == 0) return hipSuccess;
     // Small problems: 32-frame tiles do not even give every CU one workgroup (c2: 94 tiles for 256 CUs); 8-frame tiles --
     // one cell per thread -- quadruple the workgroups (RNNT_GATHER_SMALL_TILES=0 / 1 forces one or the other, for A/B runs)
-    static const int force = getenv("RNNT_GATHER_SMALL_TILES") ? atoi(getenv("RNNT_GATHER_SMALL_TILES")) : -1;
+    static const int force = ab_getenv("RNNT_GATHER_SMALL_TILES") ? atoi(ab_getenv("RNNT_GATHER_SMALL_TILES")) : -1;
     const size_t tiles32 = (size_t)N * ((T + TT - 1) / TT) * ((U + TD - 1) / TD);
     // (dense entry, us per call, 32- / 8-frame tiles: c2 28.1 / 27.4, N=32 35.1 / 33.2, N=64 46.2 / 45.2, N=128 67.1 / 68.1)
     const bool small_tiles = force >= 0 ? force != 0 : tiles32 < 512;
@@ -1632,7 +1632,7 @@ hipError_t launch_gather_compact(hipStream_t stream, const float* xs, const int*
                                  int64_t* loc, int N, int Tmax, int Umax, int V, int blank, int64_t STU) {
     if (N <= 0 || Tmax <= 0 || Umax <= 0) return hipSuccess;
     // RNNT_COMPACT_GATHER=tiles|linear pins one of the two kernels (A/B runs)
-    static const char* pin = getenv("RNNT_COMPACT_GATHER");
+    static const char* pin = ab_getenv("RNNT_COMPACT_GATHER");
     const bool want_linear = pin ? pin[0] == 'l' : true;
     if (want_linear && STU > 0 && N <= 4096) {
         const int64_t nblk = (STU + 256 * GCL_CELLS - 1) / (256 * GCL_CELLS);
@@ -1646,7 +1646,7 @@ hipError_t launch_gather_compact(hipStream_t stream, const float* xs, const int*
     const int tiles_t = (Tmax + TD - 1) / TD, tiles_u = (Umax + TD - 1) / TD;
     const size_t nblk = (size_t)N * tiles_t * tiles_u;
     if (nblk >= ((size_t)1 << 31)) return hipErrorInvalidValue;
-    static const bool plain_order = getenv("RNNT_COMPACT_PLAIN_TILE_ORDER") != nullptr;      // A/B runs
+    static const bool plain_order = ab_getenv("RNNT_COMPACT_PLAIN_TILE_ORDER") != nullptr;      // A/B runs
     k_gather_compact<<<(unsigned)nblk, 256, 0, stream>>>(xs, ys, xn, yn, offs, label_offs,
                                                          reinterpret_cast<float2*>(ws2), loc, V, blank,
                                                          tiles_t, tiles_u, N, plain_order ? 1 : 0);
