@@ -3,7 +3,7 @@
 # Copy the summaries into profiles/ afterwards with `python tools/summarise_profiles.py $TAG`.
 #   --pmc passes are separate from each other and never combined with other trace domains.
 set -u
-TAG=${1:-r05}
+TAG=${1:-r06}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
@@ -63,7 +63,6 @@ if [ -f tools/_probe/wdstats/lib.so ]; then
   python tools/wd_trace.py 16 1500 300 2>&1 | grep -v amdgpu > $OUT/wd_trace_c4.txt
 fi
 (python tools/graph_probe.py 16 150 40 28 0 1000; python tools/graph_probe.py 16 1500 300 50 1) 2>&1 | grep "N=" > $OUT/graph_probe.txt
-tools/ubench/pd_steps > $OUT/ubench_pd_steps.txt 2>&1
 python tools/host_overhead.py 2>&1 | grep -v amdgpu > $OUT/host_overhead.txt
 (echo "== ctypes fallback"; WARP_RNNT_AMD_NO_NATIVE_BINDING=1 python tools/host_overhead.py 2>&1 | grep -v amdgpu) >> $OUT/host_overhead.txt
 python tools/compact_host_probe.py 2>&1 | grep -v amdgpu > $OUT/compact_host_probe.txt

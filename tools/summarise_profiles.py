@@ -10,7 +10,7 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-TAG = sys.argv[1] if len(sys.argv) > 1 else "r05"
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r06"
 SRC = os.path.join(ROOT, "gpurun_out", TAG)
 DST = os.environ.get("PROFILES_DST") or os.path.join(ROOT, "profiles")      # (PROFILES_DST: summarise on the GPU box, into gpurun_out)
 
@@ -63,7 +63,7 @@ def main():
     for f in glob.glob(os.path.join(SRC, "table_*.md")):
         shutil.copy(f, os.path.join(DST, f"{TAG}_" + os.path.basename(f)))
     for name in ("parity_errors.json", "lattice_probe.txt", "lattice_routes.txt", "cabi_probe.txt", "wd_trace_c4.txt",
-                 "shape_map.md", "bench_c4_pd_lattice.json", "ubench_pd_steps.txt", "host_overhead.txt",
+                 "shape_map.md", "bench_c4_blocks_of_8.json", "host_overhead.txt",
                  "bench_c4_logdomain_lattice.json", "bench_c4_rccl_group.json", "bench_c4_cold_start.json",
                  "graph_probe.txt", "lsm_rate_by_size.txt", "bench_c4_n128.json", "ubench_copy_rate.txt",
                  "compact_host_probe.txt", "ubench_gather_variants.txt"):

@@ -506,9 +506,12 @@ void run_warp_rnnt_compact(unsigned int* counts, float* alphas, float* betas, co
     const bool staged = required_grad && (size_t)N * T * U >= STAGED_FROM_CELLS && reinterpret_cast<uintptr_t>(grads) % 16 == 0 &&
                         reinterpret_cast<uintptr_t>(alphas) % 8 == 0 && reinterpret_cast<uintptr_t>(betas) % 8 == 0 &&
                         grads != betas && alphas != betas;
-    if (staged) {
-        hipError_t e = launch_reskew_compact32(nullptr, log_probs, grads, xn, yn, memPref, N, T, U);
-        if (e != hipSuccess) { compact_fail(RNNT_STATUS_PROLOGUE_FAILED, "run_warp_rnnt_compact", costs, N, e); return; }
+    // (the staged form's first launch -- nothing of the caller's has been overwritten yet -- may be refused where the direct
+    //  form is not, e.g. on its 2^31-workgroup grid limit: then the direct form runs)
+    hipError_t e_stage = staged ? launch_reskew_compact32(nullptr, log_probs, grads, xn, yn, memPref, N, T, U) : hipErrorNotSupported;
+    if (staged && e_stage != hipSuccess) (void)hipGetLastError();
+    if (staged && e_stage == hipSuccess) {
+        hipError_t e;
         LatticeArgs ls{grads, nullptr, ixn, iyn, alphas, betas, ll, (int)T, (int)U, 2, 0};
         ls.offs32 = memPref;
         e = launch_lattice(nullptr, ls, (int)N, LOAD_SKEWED);
