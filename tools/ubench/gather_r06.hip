@@ -265,6 +265,19 @@ int main(int argc, char** argv) {
         run(label, [&] { k_tile<TT, TD, ORDER, HOT, X4><<<grid, 256>>>(src, labels, dst, N, T, U, V, 0, tiles_t, tiles_u); }); \
         if (chk) check(label);                                                                                        \
     }
+    if (getenv("GATHER_R06_PMC")) {
+        // counter passes (rocprofv3 --pmc around this binary): three kernels, 12 launches each, nothing else --
+        // the shipped form, the same with its stores kept in L2, and the tile-major form (sequential full-line writes)
+        TILE(32, 32, 1, false, false, out, false, "pmc: 32x32 linear reversed (shipped)")
+        TILE(32, 32, 0, true, false, out, false, "pmc: 32x32 linear, stores into a hot 64 KB buffer")
+        {
+            const int tiles_t = (T + 31) / 32, tiles_u = (U + 31) / 32;
+            const unsigned grid = grid_of(1, N, tiles_t, tiles_u);
+            run("pmc: 32x32 reversed, tile-major contiguous output",
+                [&] { k_tile<32, 32, 1, false, false, -1><<<grid, 256>>>(src, labels, out, N, T, U, V, 0, tiles_t, tiles_u); });
+        }
+        return 0;
+    }
     for (int round = 0; round < 2; ++round) {      // (twice: run-to-run drift on a box is a few us)
         TILE(32, 32, 0, false, false, ref, false, "32x32 linear (shipped shape, forward walk)")
         TILE(32, 32, 1, false, false, out, true, "32x32 linear reversed (shipped)")
