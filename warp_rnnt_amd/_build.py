@@ -69,6 +69,9 @@ VARIANTS = {
     # the build that reads the kernel-selection knobs of DESIGN.md section 10 from the environment (common.h: ab_getenv); the
     # probes under tools/ load it through WARP_RNNT_AMD_LIB -- the shipped library ignores those variables
     "ab": ["-DRNNT_AB_KNOBS"],
+    # timing probes of the fused logits -> pairs kernel's stores (WRONG results: tools/fused_store_probe.py only)
+    "probe_hot_pairs": ["-DRNNT_PROBE_HOT_PAIRS"],
+    "probe_linear_pairs": ["-DRNNT_PROBE_LINEAR_PAIRS"],
     # a build that MUST FAIL: the hand-written blocks end with two of their in-place reloads still in flight -- the bug
     # class of round 5; tests/test_host_cpu.py checks that build() refuses it (warp_rnnt_amd/_isa_check.py)
     "planted_violation": ["-DRNNT_PLANT_RELOAD_VIOLATION"],

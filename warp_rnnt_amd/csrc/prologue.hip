@@ -314,7 +314,14 @@ k_lsm_small(const float* x, float* out, const int* __restrict__ labels,
             const CellMap m = map_cell((size_t)(row0 + r), labels, T, U, V, blank);
             const float2 st = stat[r];
             const float* row = tile + r * V;
+#ifdef RNNT_PROBE_HOT_PAIRS     // timing probe (wrong results): the pairs into a 64 KB region that stays in L2 -- what the
+                                // kernel costs without its DRAM writes (the gather's stores cost 40-55 us in any shape)
+            reinterpret_cast<float2*>(out)[m.sk & 8191] =
+#elif defined(RNNT_PROBE_LINEAR_PAIRS)   // ... and with the pairs in row-major order (coalesced 512-byte runs; wrong layout)
+            reinterpret_cast<float2*>(out)[row0 + r] =
+#else
             reinterpret_cast<float2*>(out)[m.sk] =
+#endif
                 make_float2((row[blank] - st.x) - st.y, (row[m.label] - st.x) - st.y);
         }
     } else if constexpr (WP) {
