@@ -29,6 +29,28 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+
+
+def _point_rccl_debug_at_a_file():
+    """First contact with a multi-GPU node should document itself: RCCL's own account of the transports it
+    chose goes to a scratch file per rank -- INIT lines only, nothing per collective -- unless the caller already asked for
+    RCCL's debug output somewhere else.  HERE, before torch is imported: RCCL reads NCCL_DEBUG* when the library
+    initialises, and setting them from main() was measured to be too late (no file, no lines)."""
+    # (a level below INFO -- this image exports NCCL_DEBUG=VERSION -- has no channel lines to lose: raised; a caller who
+    #  asked for INFO or TRACE, or named a file, keeps what they set up)
+    if os.environ.get("NCCL_DEBUG", "VERSION").upper() not in ("VERSION", "WARN") or "NCCL_DEBUG_FILE" in os.environ \
+            or "--dry" in sys.argv:
+        return None
+    if int(os.environ.get("WORLD_SIZE", "1")) <= 1 and "--rccl-group" not in sys.argv:
+        return None
+    import tempfile
+    path = os.path.join(tempfile.gettempdir(), f"bench_rccl_{os.getpid()}_{os.environ.get('RANK', '0')}.log")
+    os.environ.update(NCCL_DEBUG="INFO", NCCL_DEBUG_SUBSYS="INIT", NCCL_DEBUG_FILE=path)
+    return path
+
+
+RCCL_LOG = _point_rccl_debug_at_a_file()
+
 import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md); ~6300 achievable
@@ -403,14 +425,7 @@ def main():
             with socket.socket() as s:
                 s.bind(("127.0.0.1", 0))
                 os.environ["MASTER_PORT"] = str(s.getsockname()[1])
-        # first contact with a multi-GPU node should document itself: RCCL's own account of the transports
-        # it chose goes to a scratch file (NCCL_DEBUG is read once, when the communicator is created; INIT lines only --
-        # nothing is logged per collective) unless the caller already asked for RCCL's debug output somewhere else
-        rccl_log = None
-        if "NCCL_DEBUG" not in os.environ:
-            import tempfile
-            rccl_log = os.path.join(tempfile.gettempdir(), f"bench_rccl_{os.getpid()}_{rank}.log")
-            os.environ.update(NCCL_DEBUG="INFO", NCCL_DEBUG_SUBSYS="INIT", NCCL_DEBUG_FILE=rccl_log)
+        rccl_log = RCCL_LOG          # (set before torch was imported: _point_rccl_debug_at_a_file)
         try:
             dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
             # ... and the communicator works: one scalar through RCCL before the batch exists (a rank that cannot reach
