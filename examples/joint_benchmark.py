@@ -8,6 +8,8 @@ broadcast, passed through tanh + Linear(H,V), and the result goes into the loss;
 
   * timing is HIP-event based with warm-up iterations (the reference uses the torch profiler table only;
     pass --profile for that table as well);
+  * `--loss warp-rnnt-lazy` keeps the reference's call shape -- `rnnt_loss(log_softmax(joint_out), ..., gather=True)` --
+    with `log_softmax` imported from `warp_rnnt_amd.functional`: the same fused path, no change of signature.
   * `--loss warp-rnnt-fused` feeds the joint's *logits* to `rnnt_loss_from_logits`, so the (N,T,U,V)
     log-probabilities and their gradient never exist -- the call chain the reference cannot express;
   * `--ddp` wraps the joint in DistributedDataParallel (one process per GPU, RCCL) and shards the batch:
@@ -28,14 +30,15 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 import torch.nn as nn  # noqa: E402
 
-LOSSES = ("warp-rnnt", "warp-rnnt-gather", "warp-rnnt-compact", "warp-rnnt-fused")
+LOSSES = ("warp-rnnt", "warp-rnnt-gather", "warp-rnnt-compact", "warp-rnnt-fused", "warp-rnnt-lazy")
 GRID = [(150, 40, 28), (150, 20, 5000), (1500, 300, 50)]      # benchmark2.py:133 (U = label count here)
 BATCHES = [1, 16, 32, 64, 128]
 
 
 class JointNetwork(nn.Module):
     """tanh(f_t + g_u) -> Linear(H, V).  `packed=True` emits the ragged (sum_n T_n*(U_n+1), V) layout of
-    rnnt_loss(compact=True); `log_softmax=False` returns logits (for the fused loss)."""
+    rnnt_loss(compact=True); `log_softmax=False` returns logits (for the fused loss); `log_softmax="lazy"` normalises with
+    warp_rnnt_amd.functional.log_softmax -- the reference's call shape, which rnnt_loss(gather=True) then fuses with."""
 
     def __init__(self, hidden: int, vocab: int, packed: bool = False, log_softmax: bool = True):
         super().__init__()
@@ -52,6 +55,9 @@ class JointNetwork(nn.Module):
         else:
             x = f.unsqueeze(2) + g.unsqueeze(1)
         out = self.proj(torch.tanh(x))
+        if self.normalise == "lazy":
+            from warp_rnnt_amd.functional import log_softmax
+            return log_softmax(out)
         return out.log_softmax(dim=-1) if self.normalise else out
 
 
@@ -86,13 +92,15 @@ def pick_loss(name):
         return compact
     if name == "warp-rnnt-fused":
         return lambda xs, ys, xn, yn: rnnt_loss_from_logits(xs, ys, xn, yn)
+    if name == "warp-rnnt-lazy":       # xs is the lazy handle of warp_rnnt_amd.functional.log_softmax: the same call as "gather"
+        return lambda xs, ys, xn, yn: rnnt_loss(xs, ys, xn, yn, gather=True)
     raise ValueError(f"Unrecognized type of loss:{name}")
 
 
 def bytes_needed(N, T, U, V, H, loss, fwd_only):
     """Rough HBM need of one step: the dense (N,T,U+1,·) tensors autograd keeps alive."""
     cells = N * T * (U + 1)
-    dense_v = {"warp-rnnt": 4, "warp-rnnt-gather": 3, "warp-rnnt-compact": 3, "warp-rnnt-fused": 2}[loss]
+    dense_v = {"warp-rnnt": 4, "warp-rnnt-gather": 3, "warp-rnnt-compact": 3, "warp-rnnt-fused": 2, "warp-rnnt-lazy": 2}[loss]
     if fwd_only:
         dense_v -= 1
     return 4 * cells * (dense_v * V + 2 * H + 16)
@@ -140,7 +148,7 @@ def main():
                     print(f"| {T} | {U} | {V} | {N_global} | skipped (shard empty or larger than HBM) | |")
                 continue
             joint = JointNetwork(args.hidden, V, packed=args.loss.endswith("compact"),
-                                 log_softmax=not args.loss.endswith("fused")).to(device)
+                                 log_softmax="lazy" if args.loss.endswith("lazy") else not args.loss.endswith("fused")).to(device)
             if args.fwd_only:
                 joint.requires_grad_(False)
             model = nn.parallel.DistributedDataParallel(joint, device_ids=[device.index]) \

@@ -7,7 +7,7 @@ global minibatch, runs `sharded_rnnt_loss` (log-softmax, gather, lattice, gradie
 oracle run on the UNSHARDED batch.  What this pins that the one-rank tests cannot: utterances really are
 independent across processes (same bits as the single-process run of the whole batch), the scalar exchange carries
 the right normalisation for 'mean' with uneven shards (5 utterances on 2 ranks: 3 + 2), and nothing in the library
-(the lattice route setting, the per-device launch counter, the hand-over rings) is confused by a second process on
+(the per-device launch counter, the hand-over rings, the sticky diagnostics words) is confused by a second process on
 the same device.
 
 The reference has no counterpart (no collective call site exists)."""
@@ -58,9 +58,9 @@ for red in ("mean", "sum", "none"):
             loss.backward(); scale = 1.0 if red == "sum" else 1.0 / N
         # d(global loss)/d(this rank's log-probs) = the oracle's gradient of the unsharded batch, this rank's rows
         np.testing.assert_allclose(lp.grad.cpu().numpy(), full["grads"][lo:hi] * scale, **tol)
-# a second process on the device must not disturb the first: both now run the long-lattice (probability-domain)
-# route at the same time on their own workspaces
-logits, labels, xn, yn = make_case(32 + rank, 2, 700, 70, 7, ragged=True)
+# a second process on the device must not disturb the first: both now run the ring kernel (k_lattice_wd: three column
+# blocks handing over through L2, its per-device launch counter, its flags and rings) at the same time on their own workspaces
+logits, labels, xn, yn = make_case(32 + rank, 2, 700, 150, 7, ragged=True)
 ref = oracle.rnnt_loss_f32(np_log_softmax32(logits), labels, xn, yn)
 dist.barrier()
 for _ in range(3):

@@ -323,7 +323,7 @@ def _load_joint_example():
 
 @pytest.mark.gpu
 def test_joint_network_all_loss_paths_agree():
-    """dense, gather, compact and fused-from-logits give the same loss and the same d/df, d/dg."""
+    """dense, gather, compact, fused-from-logits and the lazy log_softmax give the same loss and the same d/df, d/dg."""
     jb = _load_joint_example()
     N, T, U, V, H = 4, 17, 6, 23, 32
     torch.manual_seed(5)
@@ -331,7 +331,8 @@ def test_joint_network_all_loss_paths_agree():
     weights = None
     results = {}
     for name in jb.LOSSES:
-        joint = jb.JointNetwork(H, V, packed=name.endswith("compact"), log_softmax=not name.endswith("fused")).cuda()
+        joint = jb.JointNetwork(H, V, packed=name.endswith("compact"),
+                                log_softmax="lazy" if name.endswith("lazy") else not name.endswith("fused")).cuda()
         if weights is None:
             weights = {k: v.clone() for k, v in joint.state_dict().items()}
         joint.load_state_dict(weights)
@@ -355,7 +356,7 @@ def test_joint_benchmark_cli_runs(extra):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29613", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
-    for loss in ("warp-rnnt-gather", "warp-rnnt-fused", "warp-rnnt-compact"):
+    for loss in ("warp-rnnt-gather", "warp-rnnt-fused", "warp-rnnt-compact", "warp-rnnt-lazy"):
         out = subprocess.run([sys.executable, os.path.join(root, "examples", "joint_benchmark.py"), "--loss", loss,
                               "--shapes", "20,5,11", "--batches", "3", "--iters", "2", "--warmup", "1",
                               "--hidden", "16"] + extra, env=env, capture_output=True, text=True, timeout=300)
@@ -405,7 +406,7 @@ sys.stdout.buffer.write(c.detach().cpu().numpy().tobytes() + lp.grad.cpu().numpy
 # on a small grid, prints the reference's line format and writes the table
 # ---------------------------------------------------------------------------
 @pytest.mark.parametrize("loss", ["warp-rnnt", "warp-rnnt-gather", "warp-rnnt-compact", "warp-rnnt-fused",
-                                  "torch-log-softmax-gather"])
+                                  "warp-rnnt-lazy", "torch-log-softmax-gather"])
 def test_benchmark_table_cli(loss, tmp_path):
     import re
     import subprocess

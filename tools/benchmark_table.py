@@ -11,6 +11,8 @@ difference the survey asked for: `--warmup` untimed iterations first (default 1;
 --loss: warp-rnnt | warp-rnnt-gather            rnnt_loss(log_softmax(xs), ..., gather=False|True)
         warp-rnnt-compact                       rnnt_loss(log_softmax(xs) packed, ..., compact=True)
         warp-rnnt-fused                         rnnt_loss_from_logits(xs, ...) (no counterpart in the reference)
+        warp-rnnt-lazy                          rnnt_loss(warp_rnnt_amd.functional.log_softmax(xs), ..., gather=True): the
+                                                reference's call shape, fused
         torch-log-softmax-gather                F.log_softmax from torch + rnnt_loss(gather=True)
 """
 import argparse
@@ -98,6 +100,11 @@ def main():
     elif a.loss == "warp-rnnt-fused":
         def run_loss(xs, ys, xn, yn):
             return rnnt_loss_from_logits(xs, ys, xn, yn)
+    elif a.loss == "warp-rnnt-lazy":
+        from warp_rnnt_amd.functional import log_softmax as lazy_log_softmax
+
+        def run_loss(xs, ys, xn, yn):
+            return warp_rnnt.rnnt_loss(lazy_log_softmax(xs), ys, xn, yn, gather=True)
     else:
         raise ValueError("Unknown RNN-T loss")
     col = 0 if a.loss == "warp-rnnt" else 1
