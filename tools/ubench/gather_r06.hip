@@ -139,6 +139,54 @@ k_tile(const float* __restrict__ src, const int* __restrict__ labels, float2* __
     }
 }
 
+// The shipped structure with the pair stores as buffer stores carrying cache-policy bits (gfx940+: 1 = sc0, 2 = nt, 16 = sc1;
+// sc0 sc1 = system scope: written through, nothing left dirty in L2) -- do dirty lines on their way out of L2 hold back the
+// fills of the read stream (profiles/r06_gather_store_pmc.csv), and does writing THROUGH avoid it?
+template <int TT, int TD, int ORDER, int AUX>
+__global__ void __launch_bounds__(256)
+k_tile_aux(const float* __restrict__ src, const int* __restrict__ labels, float2* __restrict__ ws2, int N, int T, int U, int V,
+           int blank, int tiles_t, int tiles_u, unsigned out_bytes) {
+    constexpr int RP = 256 / TD;
+    __shared__ float2 tile[TT][TD];
+    const TileId id = tile_of<ORDER>(blockIdx.x, N, tiles_t, tiles_u);
+    if (!id.ok) return;
+    const int t0 = id.tt * TT, u0 = id.tu * TD;
+    const int ul = threadIdx.x % TD, tl0 = threadIdx.x / TD;
+    const int u = u0 + ul;
+    const size_t nbase = (size_t)id.n * T * U;
+    int lab = blank;
+    if (u < U - 1) lab = labels[(size_t)id.n * (U - 1) + u];
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(ws2, 0, (int)out_bytes, 0x00020000);
+    float2 v[TT / RP];
+#pragma unroll
+    for (int k = 0; k < TT / RP; ++k) {
+        const int tl = tl0 + RP * k, t = t0 + tl;
+        const bool ok = t < T && u < U;
+        const float* p = src + (nbase + (size_t)(ok ? t : 0) * U + (ok ? u : 0)) * (size_t)V;
+        v[k] = make_float2(__builtin_nontemporal_load(p + blank), __builtin_nontemporal_load(p + lab));
+    }
+#pragma unroll
+    for (int k = 0; k < TT / RP; ++k) tile[tl0 + RP * k][ul] = v[k];
+    __syncthreads();
+    typedef int i2v __attribute__((ext_vector_type(2)));
+#pragma unroll
+    for (int k = 0; k < (TT + TD + RP - 1) / RP; ++k) {
+        const int d = tl0 + RP * k;
+        const int tl = d - ul;
+        if (d < TT + TD - 1 && tl >= 0 && tl < TT) {
+            const int t = t0 + tl;
+            if (t < T && u < U) {
+                int r = t + u;
+                r = r >= T ? r % T : r;
+                const size_t at = nbase + (size_t)r * U + u;
+                const float2 pr = tile[tl][ul];
+                i2v q; q.x = __builtin_bit_cast(int, pr.x); q.y = __builtin_bit_cast(int, pr.y);
+                __builtin_amdgcn_raw_buffer_store_b64(q, rs, (int)(at * 8), 0, AUX);
+            }
+        }
+    }
+}
+
 // Persistent, pipelined: workgroup w walks tiles w, w + G, w + 2G, ... (ORDER as above over the virtual index); the loads
 // of the next tile are in flight while the current tile is written out of LDS.
 template <int TT, int TD, int ORDER>
@@ -292,6 +340,19 @@ int main(int argc, char** argv) {
         TILE(64, 64, 2, false, false, out, true, "64 frames x 64 columns strips per XCD")
         TILE(64, 64, 2, false, true, out, true, "64 frames x 64 columns strips per XCD, 16-byte stores")
         TILE(16, 64, 0, false, false, out, true, "16 frames x 64 columns linear")
+#define TILEA(AUX, label)                                                                                              \
+    {                                                                                                                 \
+        const int tiles_t = (T + 31) / 32, tiles_u = (U + 31) / 32;                                                   \
+        const unsigned grid = grid_of(1, N, tiles_t, tiles_u);                                                        \
+        run(label, [&] { k_tile_aux<32, 32, 1, AUX><<<grid, 256>>>(src, labels, out, N, T, U, V, 0, tiles_t, tiles_u, (unsigned)(cells * 8)); }); \
+        check(label);                                                                                                 \
+    }
+        TILEA(0, "32x32 reversed, buffer stores, default policy")
+        TILEA(17, "32x32 reversed, stores sc0 sc1 (system scope: written through)")
+        TILEA(16, "32x32 reversed, stores sc1")
+        TILEA(1, "32x32 reversed, stores sc0")
+        TILEA(19, "32x32 reversed, stores sc0 sc1 nt")
+        TILEA(2, "32x32 reversed, stores nt")
 #define TILEP(TT, TD, ORDER, PITCH, label)                                                                             \
     {                                                                                                                 \
         const int tiles_t = (T + TT - 1) / TT, tiles_u = (U + TD - 1) / TD;                                           \

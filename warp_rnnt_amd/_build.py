@@ -69,6 +69,8 @@ VARIANTS = {
     # the build that reads the kernel-selection knobs of DESIGN.md section 10 from the environment (common.h: ab_getenv); the
     # probes under tools/ load it through WARP_RNNT_AMD_LIB -- the shipped library ignores those variables
     "ab": ["-DRNNT_AB_KNOBS"],
+    # A/B: the dense gather's pair stores left dirty in L2 (rounds 1-5) instead of written through (sc1)
+    "gather_plain_stores": ["-DRNNT_GATHER_STORE_SC1=0"],
     # timing probes of the fused logits -> pairs kernel's stores (WRONG results: tools/fused_store_probe.py only)
     "probe_hot_pairs": ["-DRNNT_PROBE_HOT_PAIRS"],
     "probe_linear_pairs": ["-DRNNT_PROBE_LINEAR_PAIRS"],

@@ -314,15 +314,15 @@ k_lsm_small(const float* x, float* out, const int* __restrict__ labels,
             const CellMap m = map_cell((size_t)(row0 + r), labels, T, U, V, blank);
             const float2 st = stat[r];
             const float* row = tile + r * V;
+            const float2 pr = make_float2((row[blank] - st.x) - st.y, (row[m.label] - st.x) - st.y);
 #ifdef RNNT_PROBE_HOT_PAIRS     // timing probe (wrong results): the pairs into a 64 KB region that stays in L2 -- what the
                                 // kernel costs without its DRAM writes (the gather's stores cost 40-55 us in any shape)
-            reinterpret_cast<float2*>(out)[m.sk & 8191] =
+            reinterpret_cast<float2*>(out)[m.sk & 8191] = pr;
 #elif defined(RNNT_PROBE_LINEAR_PAIRS)   // ... and with the pairs in row-major order (coalesced 512-byte runs; wrong layout)
-            reinterpret_cast<float2*>(out)[row0 + r] =
+            reinterpret_cast<float2*>(out)[row0 + r] = pr;
 #else
-            reinterpret_cast<float2*>(out)[m.sk] =
+            reinterpret_cast<float2*>(out)[m.sk] = pr;      // (written through, sc1: +38 us at c4 -- scattered 8-byte stores need L2 to merge them)
 #endif
-                make_float2((row[blank] - st.x) - st.y, (row[m.label] - st.x) - st.y);
         }
     } else if constexpr (WP) {
         wave_sync_lds();
@@ -1280,6 +1280,13 @@ constexpr int TD = 32;   // tile edge
 #ifndef RNNT_GATHER_TT
 #define RNNT_GATHER_TT 32
 #endif
+// The dense gather's pair stores are written THROUGH (sc1) -- round 6: what its 58 MB of stores cost is dirty lines on their
+// way out of L2 holding back the fills of the read stream; written through, nothing is left dirty: the kernel
+// alone 252.0 -> 247.6 us (tools/ubench/gather_r06.hip), inside bench.py's c4 step 0.2215 -> 0.2182 ms (four interleaved
+// pairs, profiles/r06_gather_sc1_ab.txt).  sc0 sc1 the same, nt / sc0 sc1 nt worse.  -DRNNT_GATHER_STORE_SC1=0: plain stores.
+#ifndef RNNT_GATHER_STORE_SC1
+#define RNNT_GATHER_STORE_SC1 1
+#endif
 constexpr int TT = RNNT_GATHER_TT;   // frames per tile of k_to_diagonal (columns: TD)
 
 // The preparation of the ring kernel that follows in the same call (kernels.h: RingPrep; lattice_wd.hip: k_prepare is the
@@ -1342,6 +1349,13 @@ k_to_diagonal(const float* __restrict__ src, const int* __restrict__ labels, flo
             if (t < T && u < U) {
                 int r = t + u;
                 r = r >= T ? r % T : r;
+#if RNNT_GATHER_STORE_SC1
+                // written THROUGH (agent scope): nothing is left dirty in L2 for the read stream's fills to wait behind
+                // (tools/ubench/gather_r06.hip: 247.6 vs 252.0 us alone)
+                if constexpr (DENSE) {
+                    asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(ws2 + nbase + (size_t)r * U + u), "v"(tile[tl][ul]) : "memory");
+                } else
+#endif
                 ws2[nbase + (size_t)r * U + u] = tile[tl][ul];
             }
         }
