@@ -447,6 +447,26 @@ def test_the_build_refuses_a_planted_reload_violation(monkeypatch):
             assert f.read() == g.read()
 
 
+def test_the_build_refuses_inline_assembly_stores_of_more_than_64_bits(tmp_path):
+    """gfx950: a VMEM store of more than 64 bits reads its data registers up to two wait states after it issues; the compiler
+    pads its own, not one inside `asm` (found by tools/ubench/lsm_store_policy.hip's bit check in round 6).  The build
+    refuses such a store in the library's sources unless it carries its own `s_nop`; the shipped sources have none."""
+    from warp_rnnt_amd import _build, _isa_check
+    srcs = [os.path.join(_build.CSRC, x) for x in list(_build.SOURCES) + list(_build.HEADERS)]
+    _isa_check.require_no_wide_asm_stores(srcs)
+    bad = tmp_path / "bad.hip"
+    bad.write_text('__device__ void f(float4* p, float4 v) {\n'
+                   '    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");\n'
+                   '    // asm volatile("global_store_dwordx4 %0, %1, off" in a comment does not count\n'
+                   '    asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");\n'
+                   '    asm volatile("buffer_store_dwordx3 %0, %1, %2, 0 offen"\n'
+                   '                 ::"v"(v), "v"(0), "s"(0) : "memory");\n'
+                   '    asm volatile("global_store_dwordx4 %0, %1, off sc1\\n\\ts_nop 1" ::"v"(p), "v"(v) : "memory");\n}\n')
+    assert [ln for ln, _ in _isa_check.wide_asm_stores(str(bad))] == [2, 5]
+    with pytest.raises(_isa_check.ReloadCheckError, match="more than 64 bits"):
+        _isa_check.require_no_wide_asm_stores(srcs + [str(bad)])
+
+
 def test_package_self_test_ships_the_golden_data_and_skips_cleanly_without_a_gpu():
     """`python -m warp_rnnt.test` (pytorch_binding/README.md:76-79): the data file inside the package is the repository's
     golden file, byte for byte; on a machine without a GPU every case is skipped (there is no CPU path to fall back to)

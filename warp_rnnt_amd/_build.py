@@ -97,6 +97,7 @@ def build(force=False, verbose=False, extra_flags=(), variant=None):
     flags += list(extra_flags)
 
     srcs = [os.path.join(CSRC, x) for x in SOURCES]
+    _isa_check.require_no_wide_asm_stores(srcs + hdrs)       # (cheap, every call: a rule on the source text)
     fp = _fingerprint(srcs + hdrs, flags)
     if not force and os.path.exists(lib) and _read(lib + ".fingerprint") == fp:
         # built from exactly these sources with exactly these flags: nothing to do, even when the object

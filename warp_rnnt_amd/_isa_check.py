@@ -133,3 +133,41 @@ def require_clean(path, min_kernels=1, min_reloads=1):
                                f"in flight (csrc/lattice_step.h: wait_lds) -- this build would compute wrong lattices under "
                                f"load:\n{lines}")
     return kernels, reloads
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Second rule, on the SOURCES: no inline-assembly VMEM store of more than 64 bits.
+#
+# gfx940 / gfx950: a global / buffer / flat store of more than 64 bits of data reads its data registers up to two
+# wait states after it issues, and a VALU write of one of them inside that window lands in the stored value.  The
+# compiler pads its own stores (GCNHazardRecognizer); it does not look inside an `asm` statement, so an inline
+# `global_store_dwordx4 ... sc1` followed by the compiler's next VALU instruction is a coin toss.  Found in round 6 by a
+# micro-benchmark's bit check (tools/ubench/lsm_store_policy.hip: 0.18 % of the float4 of one lane group wrong, every
+# cache policy, only the inline-assembly forms); the library's one inline store is a dwordx2 (prologue.hip: the dense
+# gather's write-through pairs), which has no such window.  This rule keeps it that way; the one form it lets through is the
+# store with an `s_nop 1` of its own behind it in the same assembly string.
+WIDE_ASM_STORE = re.compile(r"\b(global|buffer|flat|scratch)_store_(dwordx[34]|b96|b128)\b")
+
+
+def wide_asm_stores(path):
+    """[(line number, text)] of inline-assembly VMEM stores of more than 64 bits in a source file: lines inside an
+    `asm` statement (from the `asm` keyword to the `;` that ends it) that name such an instruction in a string."""
+    out, in_asm = [], False
+    for i, line in enumerate(open(path).read().split("\n"), 1):
+        code = line.split("//")[0]
+        if re.search(r"\basm\b", code):
+            in_asm = True
+        if in_asm and WIDE_ASM_STORE.search(code) and not re.search(r"\\n\\ts_nop [1-9]\"", code):
+            out.append((i, line.strip()))      # (allowed: the store with its own `s_nop 1` behind it in the same string)
+        if in_asm and ";" in code.split('"')[-1]:
+            in_asm = False
+    return out
+
+
+def require_no_wide_asm_stores(paths):
+    bad = [(p, ln, t) for p in paths for ln, t in wide_asm_stores(p)]
+    if bad:
+        lines = "\n".join(f"  {p}:{ln}: {t[:120]}" for p, ln, t in bad[:12])
+        raise ReloadCheckError("inline-assembly VMEM store(s) of more than 64 bits: on gfx950 the VALU instruction the compiler "
+                               "puts behind one may overwrite the data before the store has read it (no hazard padding inside "
+                               "or after `asm`); use the compiler's store, or a dwordx2:\n" + lines)

@@ -80,6 +80,9 @@ __device__ __forceinline__ CellMap map_cell(size_t cell, const int* __restrict__
 // a read-only stream of the logits; backward: logits in, d/d logits out -- fused forward 0.472 -> 0.464 ms, fused
 // training step 1.00 -> 0.975 ms at c4, profiles/r03_bwd_nt_ab.txt), plain for the log-softmax itself, where the
 // hints measured nothing to worse in rounds 1-2 (HISTORY.md).  -DRNNT_LSM_NT forces them everywhere (A/B builds).
+// Written-through stores (sc1 / sc1 nt; round 6, after the dense gather gained from them): nothing at c4 in any mode of this
+// kernel, c3's row-per-workgroup kernel 0.658 -> 0.73-0.76 ms, the register kernel 480 -> 520-580 us -- they pay only where
+// every store instruction covers whole 128-byte lines (profiles/r06_lsm_store_policy.txt).
 typedef float rnnt_f4 __attribute__((ext_vector_type(4)));
 template <bool NT> __device__ __forceinline__ float4 lsm_load4(const float4* p) {
     if constexpr (NT) {
