@@ -467,6 +467,59 @@ def test_the_build_refuses_inline_assembly_stores_of_more_than_64_bits(tmp_path)
         _isa_check.require_no_wide_asm_stores(srcs + [str(bad)])
 
 
+def test_the_isa_walk_sees_the_wait_state_hazards_around_inline_assembly(tmp_path):
+    """_isa_check's third rule on hand-made ISA: each hazard alone, its padded form, a hazard that only exists along a
+    loop's back edge, and that compiler-only findings are reported but not fatal.  (The shipped objects pass the same
+    walk inside _build.build(): HAZARD_CHECKED.)"""
+    from warp_rnnt_amd import _build, _isa_check
+
+    def isa(body):
+        f = tmp_path / f"k{abs(hash(body))}.s"
+        f.write_text("_Z1kv:\n" + body + "\ts_endpgm\n")
+        return str(f)
+
+    A, E = "\t;;#ASMSTART\n", "\t;;#ASMEND\n"
+    dpp = "\tv_mov_b32_dpp v4, v1 wave_shr:1 row_mask:0xf bank_mask:0xf\n"
+    # the compiler's instruction one slot in front of an inline DPP read of its result
+    bad = isa("\tv_add_f32_e32 v1, v2, v3\n\tds_write_b32 v9, v8\n" + A + dpp + E)
+    assert [f[3][:8] for f in _isa_check.check_hazards(bad)[2]] == ["DPP read"]
+    with pytest.raises(_isa_check.AsmHazardError, match="DPP read of v1 1 wait"):
+        _isa_check.require_no_asm_hazards(bad)
+    # two slots: fine; s_nop 1 counts two; only the DPP operand (first source) matters
+    for ok in ("\tv_add_f32_e32 v1, v2, v3\n\tds_write_b32 v9, v8\n\tv_add_f32_e32 v7, v2, v3\n" + A + dpp + E,
+               "\tv_add_f32_e32 v1, v2, v3\n\ts_nop 1\n" + A + dpp + E,
+               "\tv_add_f32_e32 v1, v2, v3\n" + A + "\tv_sub_f32_dpp v2, v50, v1 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n" + E):
+        assert _isa_check.require_no_asm_hazards(isa(ok))[2] == []
+    # a transcendental's result in the next slot; one instruction between is enough; trans -> trans is no hazard
+    with pytest.raises(_isa_check.AsmHazardError, match="transcendental"):
+        _isa_check.require_no_asm_hazards(isa(A + "\tv_exp_f32 v5, v1\n\tv_add_f32 v6, 1.0, v5\n" + E))
+    _isa_check.require_no_asm_hazards(isa(A + "\tv_exp_f32 v5, v1\n\tv_max_f32 v7, v1, v2\n\tv_add_f32 v6, 1.0, v5\n" + E))
+    _isa_check.require_no_asm_hazards(isa(A + "\tv_exp_f32 v5, v1\n\tv_log_f32 v6, v5\n" + E))
+    # the wide store: the finding of tools/ubench/lsm_store_policy.hip
+    with pytest.raises(_isa_check.AsmHazardError, match="more than 64 bits"):
+        _isa_check.require_no_asm_hazards(isa(A + "\tglobal_store_dwordx4 v[12:13], v[4:7], off sc1\n" + E +
+                                              "\ts_or_b64 exec, exec, s[10:11]\n\tv_max_f32_e32 v4, v19, v19\n"))
+    _isa_check.require_no_asm_hazards(isa(A + "\tglobal_store_dwordx4 v[12:13], v[4:7], off sc1\n\ts_nop 1\n" + E +
+                                          "\tv_max_f32_e32 v4, v19, v19\n"))
+    _isa_check.require_no_asm_hazards(isa(A + "\tglobal_store_dwordx2 v[12:13], v[4:5], off sc1\n" + E + "\tv_max_f32_e32 v4, v19, v19\n"))
+    # only along the back edge: the loop's last instruction writes what its first instruction reads through DPP
+    loop = isa("\tv_mov_b32_e32 v1, 0\n\ts_nop 4\n.LBB0_1:\n" + A + dpp + "\tv_add_f32 v9, v4, v4\n\tv_add_f32 v1, v4, v9\n" + E +
+               "\ts_cbranch_scc1 .LBB0_1\n")
+    with pytest.raises(_isa_check.AsmHazardError, match="DPP read of v1 1 wait"):
+        _isa_check.require_no_asm_hazards(loop)
+    # between two compiler instructions: the model's problem, not the build's
+    nk, ni, rest = _isa_check.require_no_asm_hazards(isa("\tv_exp_f32_e32 v5, v1\n\tv_add_f32_e32 v6, v5, v5\n"))
+    assert (nk, ni, len(rest)) == (1, 3, 1)
+    assert set(_build.HAZARD_CHECKED) <= set(_build.SOURCES) and "lattice_wd.hip" in _build.HAZARD_CHECKED
+    # every source that holds inline assembly is on the list
+    import re
+    for src in _build.SOURCES:
+        text = open(os.path.join(_build.CSRC, src)).read()
+        incs = re.findall(r'#include "(\w+\.h)"', text)
+        holds = any(re.search(r"\basm\b", open(os.path.join(_build.CSRC, f)).read()) for f in [src] + incs)
+        assert holds == (src in _build.HAZARD_CHECKED), src
+
+
 def test_package_self_test_ships_the_golden_data_and_skips_cleanly_without_a_gpu():
     """`python -m warp_rnnt.test` (pytorch_binding/README.md:76-79): the data file inside the package is the repository's
     golden file, byte for byte; on a machine without a GPU every case is skipped (there is no CPU path to fall back to)

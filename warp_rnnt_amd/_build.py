@@ -22,6 +22,10 @@ ARCH = "gfx950"
 # shipped two silent wrong-answer bugs of this family).  Value: (kernels, in-place reloads) the file is known to hold at
 # least -- a check that no longer finds them must not pass.
 RELOAD_CHECKED = {"lattice_wd.hip": (8, 600)}
+# Sources with inline assembly of any kind: their ISA is walked for the wait-state hazards the compiler's recognizer does
+# not resolve around an `asm` statement (_isa_check: third rule -- DPP behind a VALU write, a transcendental's result in
+# the next slot, a VALU write behind a wide store).  Value: kernels the file is known to hold at least.
+HAZARD_CHECKED = {"lattice_wd.hip": 8, "lattice.hip": 4, "lattice_ws.hip": 2, "prologue.hip": 60}
 
 
 def _hipcc():
@@ -109,21 +113,24 @@ def build(force=False, verbose=False, extra_flags=(), variant=None):
         s = os.path.join(CSRC, src)
         o = os.path.join(objdir, src.replace(".hip", ".o"))
         checked = RELOAD_CHECKED.get(src)
+        hazard_checked = HAZARD_CHECKED.get(src)
         ok_mark = o + ".reloads_ok"
-        if force or _stale(o, [s] + hdrs) or (checked and _read(ok_mark) != fp):
+        if force or _stale(o, [s] + hdrs) or ((checked or hazard_checked) and _read(ok_mark) != fp):
             # (the files with hand-placed LDS reloads are compiled through their assembly text, -save-temps=obj, so that
             #  what is checked below is what is assembled into the object -- not a second compilation's output)
-            cmd = [hipcc] + flags + (["-save-temps=obj"] if checked else []) + ["-c", s, "-o", o]
+            cmd = [hipcc] + flags + (["-save-temps=obj"] if (checked or hazard_checked) else []) + ["-c", s, "-o", o]
             if verbose:
                 print(" ".join(cmd), flush=True)
             if os.path.exists(ok_mark):
                 os.remove(ok_mark)
             subprocess.check_call(cmd)
-            if checked:
+            if checked or hazard_checked:
                 isa = os.path.join(objdir, src.replace(".hip", "") + "-hip-amdgcn-amd-amdhsa-" + ARCH + ".s")
                 stem = os.path.join(objdir, src.replace(".hip", ""))
                 try:
-                    kernels, reloads = _isa_check.require_clean(isa, *checked)
+                    kernels, reloads = _isa_check.require_clean(isa, *checked) if checked else (0, 0)
+                    if hazard_checked:
+                        hk, hi, _ = _isa_check.require_no_asm_hazards(isa, hazard_checked)
                 except _isa_check.ReloadCheckError:
                     os.remove(o)          # nothing links against an object that failed its check (its ISA stays, to look at)
                     raise
@@ -134,8 +141,11 @@ def build(force=False, verbose=False, extra_flags=(), variant=None):
                             os.remove(full)
                     if os.path.exists(stem + ".hip-hip-amdgcn-amd-amdhsa.hipfb"):
                         os.remove(stem + ".hip-hip-amdgcn-amd-amdhsa.hipfb")
-                if verbose:
+                if verbose and checked:
                     print(f"{src}: {kernels} lattice kernels, {reloads} in-place LDS reloads checked, 0 violations", flush=True)
+                if verbose and hazard_checked:
+                    print(f"{src}: {hk} kernels, {hi} instructions walked for wait-state hazards around inline assembly, 0 found",
+                          flush=True)
                 with open(ok_mark, "w") as f:
                     f.write(fp)
         return o

@@ -171,3 +171,176 @@ def require_no_wide_asm_stores(paths):
         raise ReloadCheckError("inline-assembly VMEM store(s) of more than 64 bits: on gfx950 the VALU instruction the compiler "
                                "puts behind one may overwrite the data before the store has read it (no hazard padding inside "
                                "or after `asm`); use the compiler's store, or a dwordx2:\n" + lines)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Third rule, on the generated ISA: the manually-inserted-wait-state hazards of gfx940 / gfx950 that the compiler's hazard
+# recognizer resolves for its own instructions and cannot resolve for (or against) the inside of an `asm` statement:
+#   * a DPP instruction reads, through the DPP path (its first source), a VGPR a VALU instruction wrote fewer than 2 wait
+#     states before; a DPP instruction fewer than 5 wait states behind a VALU write of EXEC;
+#   * an ordinary VALU instruction reads the result of a transcendental (v_exp / v_log / v_rcp / v_rsq / v_sqrt / v_sin /
+#     v_cos) in the very next slot (1 wait state needed);
+#   * a VALU instruction writes a data register of a VMEM store of more than 64 bits fewer than 2 wait states behind it
+#     (the second rule above, seen from the ISA side).
+# The hand-written lattice steps (csrc/lattice_step.h) keep these "by construction" -- and by one instruction the COMPILER
+# places between two statements (the store of the cell's value).  This makes the construction a checked property of every
+# build: forward data flow over all edges of each kernel's control-flow graph, the state being the wait states since the
+# last such write of each register (capped), merged by minimum.  `s_nop N` counts N + 1 wait states, everything else 1.
+# Only findings with an inline-assembly instruction on one side fail the build (a finding between two compiler
+# instructions would be an error of this model, not of the compiler: reported, not fatal -- none so far).
+TRANS = re.compile(r"^v_(exp|log|rcp|rsq|sqrt|sin|cos)(_legacy|_iflag|_clamp)?_(f32|f16|f64|bf16)")
+DPPCTL = re.compile(r"quad_perm:|row_shl:|row_shr:|row_ror:|wave_shl|wave_shr|wave_rol|wave_ror|row_mirror|row_half_mirror|"
+                    r"row_bcast|row_newbcast")
+WIDE_STORE_ISA = re.compile(r"^(?:global|flat|scratch)_store_(?:dwordx3|dwordx4|b96|b128)\s+\S+,\s*(v\[\d+:\d+\])|"
+                            r"^buffer_store_(?:dwordx3|dwordx4|b96|b128)\s+(v\[\d+:\d+\])")
+HAZARD_CAP = 6
+
+
+class AsmHazardError(ReloadCheckError):
+    """An inline-assembly instruction sits inside a hazard window the compiler does not pad."""
+
+
+def _operands(text):
+    m = re.match(r"^(\S+)\s*(.*)$", text)
+    rest = m.group(2)
+    return m.group(1), ([o.strip() for o in re.split(r",(?![^\[]*\])", rest)] if rest else [])
+
+
+def check_hazards(path):
+    """Returns (kernels, instructions, [(function, line, text, what, involves inline assembly)])."""
+    lines = open(path).read().split("\n")
+    funcs, cur = [], None
+    for i, line in enumerate(lines):
+        m = re.match(r"^(_Z\w+):", line)
+        if m:
+            cur = [m.group(1), i, None]
+            funcs.append(cur)
+        elif cur is not None and cur[2] is None and re.match(r"^\s*s_endpgm", line):
+            cur[2] = i
+    found, nk, ni = [], 0, 0
+    for fn, start, end in funcs:
+        if end is None:
+            continue
+        nk += 1
+        insts, labels, in_asm = [], {}, False
+        for i in range(start + 1, end + 1):
+            raw = lines[i]
+            st = raw.strip()
+            if st.startswith(";;#ASMSTART"):
+                in_asm = True; continue
+            if st.startswith(";;#ASMEND"):
+                in_asm = False; continue
+            lm = re.match(r"^(\.LBB\w+):", raw)
+            if lm:
+                labels[lm.group(1)] = len(insts); continue
+            t = raw.split(";")[0].strip()
+            if not t or t.startswith(".") or re.match(r"^\.?\w+:", t):
+                continue
+            insts.append((i + 1, t, in_asm))
+        n = len(insts)
+        ni += n
+        succ = [[] for _ in range(n)]
+        dec = []
+        for k, (_, t, _) in enumerate(insts):
+            if not t.startswith("s_endpgm"):
+                b = re.match(r"^s_c?branch\w*\s+(\.LBB\w+)", t)
+                if b and b.group(1) in labels and labels[b.group(1)] < n:
+                    succ[k].append(labels[b.group(1)])
+                if not t.startswith("s_branch") and k + 1 < n:
+                    succ[k].append(k + 1)
+            mn, ops = _operands(t)
+            valu = mn.startswith("v_")
+            d = dict(ws=(int(ops[0], 0) + 1) if mn == "s_nop" else 1, valu=valu, trans=bool(TRANS.match(mn)),
+                     dpp=valu and ("_dpp" in mn or bool(DPPCTL.search(t))), dst=set(), src=set(), dppsrc=set(), wide=set(),
+                     cmpx=mn.startswith("v_cmpx"))
+            if valu and ops:
+                has_vdst = bool(re.match(r"^v(\d+|\[)", ops[0]))
+                d["dst"] = regs_of(ops[0]) if has_vdst else set()
+                if mn.startswith("v_swap"):
+                    d["dst"] |= regs_of(ops[1])
+                srcs = ops[1:]
+                d["src"] = set().union(*[regs_of(o) for o in srcs]) if srcs else set()
+                if "mac" in mn:                         # (v_fmac / v_mac accumulate into their destination)
+                    d["src"] |= d["dst"]
+                if d["dpp"] and srcs:
+                    d["dppsrc"] = regs_of(srcs[0])      # the operand that goes through the DPP path
+            w = WIDE_STORE_ISA.match(t)
+            if w:
+                d["wide"] = regs_of(w.group(1) or w.group(2))
+            dec.append(d)
+        state_in = [None] * n           # {(kind, register): (wait states since, written inside inline assembly?)}
+        state_in[0] = {}
+        work, reported = [0], set()
+
+        def report(ln, t, kind, what, asm_side):
+            if (ln, kind) not in reported:
+                reported.add((ln, kind))
+                found.append((fn, ln, t, what, asm_side))
+
+        while work:
+            k = work.pop()
+            ln, t, a = insts[k]
+            d, st = dec[k], state_in[k]
+            if d["valu"]:
+                for r in d["dppsrc"]:
+                    e = st.get(("v", r))
+                    if e and e[0] < 2:
+                        report(ln, t, "dpp", f"DPP read of v{r} {e[0]} wait state(s) behind its VALU write (2 needed)", a or e[1])
+                if d["dpp"]:
+                    e = st.get(("x", 0))
+                    if e and e[0] < 5:
+                        report(ln, t, "exec", f"DPP {e[0]} wait state(s) behind a VALU write of EXEC (5 needed)", a or e[1])
+                if not d["trans"]:
+                    for r in d["src"]:
+                        e = st.get(("t", r))
+                        if e and e[0] < 1:
+                            report(ln, t, "trans", f"VALU read of v{r} in the slot behind the transcendental that wrote it "
+                                                   f"(1 wait state needed)", a or e[1])
+                for r in d["dst"]:
+                    e = st.get(("w", r))
+                    if e and e[0] < 2:
+                        report(ln, t, "wide", f"VALU write of v{r} {e[0]} wait state(s) behind a store of more than 64 bits that "
+                                              f"reads it (2 needed)", a or e[1])
+            out = {}
+            for key, (age, ia) in st.items():
+                if age + d["ws"] < HAZARD_CAP:
+                    out[key] = (age + d["ws"], ia)
+            if d["valu"]:
+                for r in d["dst"]:
+                    out[("v", r)] = (0, a)
+                    if d["trans"]:
+                        out[("t", r)] = (0, a)
+                    else:
+                        out.pop(("t", r), None)
+                if d["cmpx"]:
+                    out[("x", 0)] = (0, a)
+            for r in d["wide"]:
+                out[("w", r)] = (0, a)
+            for s_ in succ[k]:
+                cur_ = state_in[s_]
+                if cur_ is None:
+                    state_in[s_] = dict(out)
+                    work.append(s_)
+                    continue
+                changed = False
+                for key, v in out.items():
+                    c = cur_.get(key)
+                    if c is None or v[0] < c[0] or (v[0] == c[0] and v[1] and not c[1]):
+                        cur_[key] = (v[0], v[1] or (c is not None and c[0] == v[0] and c[1]))
+                        changed = True
+                if changed:
+                    work.append(s_)
+    return nk, ni, found
+
+
+def require_no_asm_hazards(path, min_kernels=1):
+    """check_hazards(path) as a gate: raises AsmHazardError when a finding has an inline-assembly instruction on either side.
+    Returns (kernels, instructions, findings between compiler instructions only)."""
+    nk, ni, found = check_hazards(path)
+    if nk < min_kernels:
+        raise AsmHazardError(f"{path}: {nk} kernels found, expected at least {min_kernels}: the check no longer sees its input")
+    bad = [f for f in found if f[4]]
+    if bad:
+        lines = "\n".join(f"  line {ln}: `{text}`: {what}   [{fn[:60]}]" for fn, ln, text, what, _ in bad[:12])
+        raise AsmHazardError(f"{path}: {len(bad)} hazard(s) the compiler does not pad around inline assembly:\n{lines}")
+    return nk, ni, [f for f in found if not f[4]]

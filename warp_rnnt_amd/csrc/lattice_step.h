@@ -200,6 +200,7 @@ __device__ __forceinline__ void compute_block(const f32x2 (&cur)[K], const float
 // Hazards kept by construction (the compiler does not look inside): >= 2 instructions between the VALU write of the
 // value handed right and the DPP read of it (the store + one add), one instruction between v_exp_f32 / v_log_f32 and the
 // first ordinary VALU read of their result (v_max; v_add + v_sub).
+// Round 6: checked on every build instead of assumed (_isa_check.check_hazards walks the ISA of the object that ships).
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) float lds_float;   // (a pointer that can only be LDS: ds_write, never flat_store)
 
