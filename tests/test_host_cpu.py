@@ -502,6 +502,15 @@ def test_the_isa_walk_sees_the_wait_state_hazards_around_inline_assembly(tmp_pat
     _isa_check.require_no_asm_hazards(isa(A + "\tglobal_store_dwordx4 v[12:13], v[4:7], off sc1\n\ts_nop 1\n" + E +
                                           "\tv_max_f32_e32 v4, v19, v19\n"))
     _isa_check.require_no_asm_hazards(isa(A + "\tglobal_store_dwordx2 v[12:13], v[4:5], off sc1\n" + E + "\tv_max_f32_e32 v4, v19, v19\n"))
+    # the LDS-DMA loads: descriptor / offset / LDS base out of v_readfirstlane need 5 wait states before a VMEM read; M0 needs 1
+    dma = "\tbuffer_load_dwordx4 v1, s[4:7], s9 offen sc1 lds\n"
+    with pytest.raises(_isa_check.AsmHazardError, match="VMEM read of s9 4 wait"):
+        _isa_check.require_no_asm_hazards(isa("\tv_readfirstlane_b32 s9, v3\n\ts_nop 1\n" + A + "\ts_mov_b32 m0, s3\n\ts_nop 0\n" + dma + E))
+    with pytest.raises(_isa_check.AsmHazardError, match="VMEM read of s6"):
+        _isa_check.require_no_asm_hazards(isa("\tv_readfirstlane_b32 s6, v3\n" + A + "\ts_mov_b32 m0, s3\n\ts_nop 0\n" + dma + E))
+    with pytest.raises(_isa_check.AsmHazardError, match="behind the write of M0"):
+        _isa_check.require_no_asm_hazards(isa(A + "\ts_mov_b32 m0, s3\n" + dma + E))
+    _isa_check.require_no_asm_hazards(isa("\tv_readfirstlane_b32 s9, v3\n\ts_nop 2\n" + A + "\ts_mov_b32 m0, s3\n\ts_nop 0\n" + dma + E))
     # only along the back edge: the loop's last instruction writes what its first instruction reads through DPP
     loop = isa("\tv_mov_b32_e32 v1, 0\n\ts_nop 4\n.LBB0_1:\n" + A + dpp + "\tv_add_f32 v9, v4, v4\n\tv_add_f32 v1, v4, v9\n" + E +
                "\ts_cbranch_scc1 .LBB0_1\n")

@@ -181,7 +181,10 @@ def require_no_wide_asm_stores(paths):
 #   * an ordinary VALU instruction reads the result of a transcendental (v_exp / v_log / v_rcp / v_rsq / v_sqrt / v_sin /
 #     v_cos) in the very next slot (1 wait state needed);
 #   * a VALU instruction writes a data register of a VMEM store of more than 64 bits fewer than 2 wait states behind it
-#     (the second rule above, seen from the ISA side).
+#     (the second rule above, seen from the ISA side);
+#   * a VMEM instruction reads an SGPR a VALU instruction (v_readfirstlane, v_readlane, a compare) wrote fewer than 5 wait
+#     states before -- the descriptor, offset and LDS base of the inline LDS-DMA loads come out of v_readfirstlane;
+#   * an LDS-DMA load (`... lds`) in the slot behind the SALU write of M0 (1 wait state needed).
 # The hand-written lattice steps (csrc/lattice_step.h) keep these "by construction" -- and by one instruction the COMPILER
 # places between two statements (the store of the cell's value).  This makes the construction a checked property of every
 # build: forward data flow over all edges of each kernel's control-flow graph, the state being the wait states since the
@@ -193,7 +196,21 @@ DPPCTL = re.compile(r"quad_perm:|row_shl:|row_shr:|row_ror:|wave_shl|wave_shr|wa
                     r"row_bcast|row_newbcast")
 WIDE_STORE_ISA = re.compile(r"^(?:global|flat|scratch)_store_(?:dwordx3|dwordx4|b96|b128)\s+\S+,\s*(v\[\d+:\d+\])|"
                             r"^buffer_store_(?:dwordx3|dwordx4|b96|b128)\s+(v\[\d+:\d+\])")
+SREG = re.compile(r"\bs(\d+)\b|\bs\[(\d+):(\d+)\]")
+VMEM = re.compile(r"^(buffer|tbuffer|global|flat|scratch|image)_")
 HAZARD_CAP = 6
+
+
+def sregs_of(text):
+    out = set()
+    for m in SREG.finditer(text):
+        if m.group(1) is not None:
+            out.add(int(m.group(1)))
+        else:
+            out.update(range(int(m.group(2)), int(m.group(3)) + 1))
+    if re.search(r"\bvcc\b", text):
+        out.add("vcc")
+    return out
 
 
 class AsmHazardError(ReloadCheckError):
@@ -267,6 +284,18 @@ def check_hazards(path):
             w = WIDE_STORE_ISA.match(t)
             if w:
                 d["wide"] = regs_of(w.group(1) or w.group(2))
+            d["sdst"] = set()
+            if valu and ops:        # SGPRs a VALU instruction writes: readlane / readfirstlane, e64 compares, carry outs
+                if not re.match(r"^v(\d+|\[)", ops[0]):
+                    d["sdst"] = sregs_of(ops[0])
+                elif len(ops) > 1 and re.match(r"^v_(add|sub|subrev|addc|subb|subbrev)_co|^v_mad_[ui]64|^v_div_scale", mn):
+                    d["sdst"] = sregs_of(ops[1])
+                if mn.startswith("v_cmp") and mn.endswith("_e32"):
+                    d["sdst"] = {"vcc"}
+            d["vmem"] = bool(VMEM.match(mn))
+            d["ssrc"] = sregs_of(t) if d["vmem"] else set()
+            d["m0w"] = mn.startswith("s_") and bool(ops) and ops[0] == "m0"
+            d["ldsdma"] = d["vmem"] and bool(re.search(r"\blds\b", t))
             dec.append(d)
         state_in = [None] * n           # {(kind, register): (wait states since, written inside inline assembly?)}
         state_in[0] = {}
@@ -301,6 +330,14 @@ def check_hazards(path):
                     if e and e[0] < 2:
                         report(ln, t, "wide", f"VALU write of v{r} {e[0]} wait state(s) behind a store of more than 64 bits that "
                                               f"reads it (2 needed)", a or e[1])
+            if d["vmem"]:
+                for r in d["ssrc"]:
+                    e = st.get(("s", r))
+                    if e and e[0] < 5:
+                        report(ln, t, "sgpr", f"VMEM read of s{r} {e[0]} wait state(s) behind its VALU write (5 needed)", a or e[1])
+                e = st.get(("m", 0))
+                if d["ldsdma"] and e and e[0] < 1:
+                    report(ln, t, "m0", "LDS-DMA in the slot behind the write of M0 (1 wait state needed)", a or e[1])
             out = {}
             for key, (age, ia) in st.items():
                 if age + d["ws"] < HAZARD_CAP:
@@ -314,6 +351,10 @@ def check_hazards(path):
                         out.pop(("t", r), None)
                 if d["cmpx"]:
                     out[("x", 0)] = (0, a)
+                for r in d["sdst"]:
+                    out[("s", r)] = (0, a)
+            if d["m0w"]:
+                out[("m", 0)] = (0, a)
             for r in d["wide"]:
                 out[("w", r)] = (0, a)
             for s_ in succ[k]:
