@@ -511,6 +511,9 @@ def test_the_isa_walk_sees_the_wait_state_hazards_around_inline_assembly(tmp_pat
     with pytest.raises(_isa_check.AsmHazardError, match="behind the write of M0"):
         _isa_check.require_no_asm_hazards(isa(A + "\ts_mov_b32 m0, s3\n" + dma + E))
     _isa_check.require_no_asm_hazards(isa("\tv_readfirstlane_b32 s9, v3\n\ts_nop 2\n" + A + "\ts_mov_b32 m0, s3\n\ts_nop 0\n" + dma + E))
+    # (a scalar instruction that overwrites the SGPR in between makes the VALU write dead: a carry-out nobody reads)
+    _isa_check.require_no_asm_hazards(isa("\tv_mad_u64_u32 v[22:23], s[10:11], v9, s54, v[2:3]\n\ts_mov_b32 s10, 0\n\ts_movk_i32 s11, 0x3000\n" + A +
+                                          "\ts_mov_b32 m0, s11\n\ts_nop 0\n\tbuffer_load_dwordx4 v22, s[36:39], s10 offen lds\n" + E))
     # only along the back edge: the loop's last instruction writes what its first instruction reads through DPP
     loop = isa("\tv_mov_b32_e32 v1, 0\n\ts_nop 4\n.LBB0_1:\n" + A + dpp + "\tv_add_f32 v9, v4, v4\n\tv_add_f32 v1, v4, v9\n" + E +
                "\ts_cbranch_scc1 .LBB0_1\n")

@@ -102,7 +102,7 @@ def build(force=False, verbose=False, extra_flags=(), variant=None):
 
     srcs = [os.path.join(CSRC, x) for x in SOURCES]
     _isa_check.require_no_wide_asm_stores(srcs + hdrs)       # (cheap, every call: a rule on the source text)
-    fp = _fingerprint(srcs + hdrs, flags)
+    fp = _fingerprint(srcs + hdrs + [_isa_check.__file__], flags)     # (a changed gate re-examines what it guards)
     if not force and os.path.exists(lib) and _read(lib + ".fingerprint") == fp:
         # built from exactly these sources with exactly these flags: nothing to do, even when the object
         # files are absent and whatever the file times say (only the .so and this sidecar travel to the

@@ -295,6 +295,10 @@ def check_hazards(path):
             d["vmem"] = bool(VMEM.match(mn))
             d["ssrc"] = sregs_of(t) if d["vmem"] else set()
             d["m0w"] = mn.startswith("s_") and bool(ops) and ops[0] == "m0"
+            # SGPRs a scalar instruction overwrites (a later reader sees the scalar value: the VALU write before it is dead)
+            d["skill"] = (sregs_of(ops[0]) if mn.startswith("s_") and ops and re.match(r"^(s\d+|s\[|vcc)", ops[0]) and not
+                          re.match(r"^s_(cmp|cmpk|bitcmp|cbranch|branch|waitcnt|nop|set|sleep|barrier|sendmsg|store|buffer_store|"
+                                   r"dcache|icache|endpgm|trap|ttrace|code_end)", mn) else set())
             d["ldsdma"] = d["vmem"] and bool(re.search(r"\blds\b", t))
             dec.append(d)
         state_in = [None] * n           # {(kind, register): (wait states since, written inside inline assembly?)}
@@ -353,6 +357,8 @@ def check_hazards(path):
                     out[("x", 0)] = (0, a)
                 for r in d["sdst"]:
                     out[("s", r)] = (0, a)
+            for r in d["skill"]:
+                out.pop(("s", r), None)
             if d["m0w"]:
                 out[("m", 0)] = (0, a)
             for r in d["wide"]:
