@@ -422,6 +422,17 @@ def test_in_place_reloads_of_the_lattice_kernels_are_not_touched_before_their_wa
     with open(bpath, "w") as f:
         f.write(broken)
     assert len(chk.check(bpath)[2]) == 1
+    # the same ISA under the wait-state walk: clean as generated; and the ONE instruction the compiler places between two
+    # hand-written steps (the store of the cell's value) is what keeps the DPP read two wait states behind its operand --
+    # take it out and the walk says so
+    nk, ni, found = chk.check_hazards(path)
+    assert nk >= 8 and ni > 50000 and not found, found[:5]
+    m = re.search(r"(\t;;#ASMEND\n)\tds_write_b32 v\d+, v\d+\n(\t;;#ASMSTART\n\tv_(?:sub_f32|mov_b32)_dpp )", text)
+    assert m
+    with open(bpath, "w") as f:
+        f.write(text.replace(m.group(0), m.group(1) + m.group(2), 1))
+    found = chk.check_hazards(bpath)[2]
+    assert found and all(f[4] and "DPP read" in f[3] for f in found), found[:5]
 
 
 def test_the_build_refuses_a_planted_reload_violation(monkeypatch):

@@ -1,6 +1,7 @@
 #!/usr/bin/env python
-"""Command-line form of warp_rnnt_amd/_isa_check.py (the static check of the lattice kernels' in-place LDS reloads that
-`_build.build()` runs on every build and that fails the build on a violation -- read that module's header first).
+"""Command-line form of warp_rnnt_amd/_isa_check.py (the static checks `_build.build()` runs on every build and that fail the
+build on a violation -- read that module's header first): the lattice kernels' in-place LDS reloads, and the wait-state
+hazards the compiler does not pad around inline assembly.
 
     python tools/check_inplace_reloads.py [file.s]        exit status 1 on a violation
 
@@ -13,7 +14,7 @@ import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from warp_rnnt_amd._isa_check import check, regs_of, RELOAD, ReloadCheckError, require_clean  # noqa: E402,F401
+from warp_rnnt_amd._isa_check import check, check_hazards  # noqa: E402
 
 CSRC = os.path.join(ROOT, "warp_rnnt_amd", "csrc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-function", "-fno-slp-vectorize"]
@@ -36,7 +37,13 @@ def main():
     print(f"{path}: {kernels} lattice kernels, {reloads} in-place reloads checked, {len(bad)} violation(s)")
     for fn, ln, text, regs in bad[:40]:
         print(f"  line {ln}: `{text}` touches v{regs} while its reload is in flight   [{fn[:60]}]")
-    return 1 if bad or reloads == 0 else 0
+    nk, ni, found = check_hazards(path)
+    fatal = [f for f in found if f[4]]
+    print(f"{path}: {nk} kernels, {ni} instructions walked for wait-state hazards, {len(fatal)} around inline assembly, "
+          f"{len(found) - len(fatal)} between compiler instructions")
+    for fn, ln, text, what, asm_side in found[:40]:
+        print(f"  line {ln}: `{text}`: {what}{'' if asm_side else '   (compiler only)'}   [{fn[:60]}]")
+    return 1 if bad or fatal or (reloads == 0 and len(sys.argv) < 2) else 0
 
 
 if __name__ == "__main__":
