@@ -74,6 +74,48 @@ __global__ void __launch_bounds__(256) k_lsm_rp(const f4* __restrict__ x, f4* __
         if (act && p < npairs) store4<SP>(out + p * 25 + j, r);
     }
 }
+// The same kernel with its results leaving through LDS in LINEAR order: the wave's four row pairs are 1600 contiguous bytes
+// (25 granules of 64 bytes); written to a per-wave LDS strip at their offsets and read back 16 bytes per lane in address
+// order, they leave as one store instruction of 1024 bytes and one of 576 -- every store instruction covers whole 64-byte
+// granules, where the direct form's 400-byte segments split them (tools/ubench/copy_shape.hip: stores off the 64-byte
+// grid cost a copy 5-19 %, loads off it nothing).  No workgroup barrier: the strip is the wave's own.
+template <bool LNT, int SP>
+__global__ void __launch_bounds__(256) k_lsm_rp_lin(const f4* __restrict__ x, f4* __restrict__ out, size_t npairs) {
+    __shared__ f4 strip[4][100];
+    const int lane = threadIdx.x & 63, j = lane & 31, half = lane >> 5, wv = threadIdx.x >> 6;
+    const size_t w = (size_t)blockIdx.x * 4 + wv;
+    const bool act = j < 25;
+    f4 v[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const size_t p = (w * 2 + i) * 2 + half;
+        v[i] = f4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        if (act && p < npairs) v[i] = load4<LNT>(x + p * 25 + j);
+    }
+    const bool a01 = j <= 12, a23 = j < 12;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const f4 t = v[i];
+        const float m01 = fmaxf(t.x, t.y), m23 = fmaxf(t.z, t.w);
+        const float ma = half_max(a23 ? fmaxf(m01, m23) : (a01 ? m01 : -INFINITY));
+        const float mb = half_max(a23 ? -INFINITY : (a01 ? m23 : fmaxf(m01, m23)));
+        const float k01 = (a01 ? ma : mb) * LOG2E, k23 = (a23 ? ma : mb) * LOG2E;
+        const float e0 = __builtin_amdgcn_exp2f(__builtin_fmaf(t.x, LOG2E, -k01)), e1 = __builtin_amdgcn_exp2f(__builtin_fmaf(t.y, LOG2E, -k01));
+        const float e2 = __builtin_amdgcn_exp2f(__builtin_fmaf(t.z, LOG2E, -k23)), e3 = __builtin_amdgcn_exp2f(__builtin_fmaf(t.w, LOG2E, -k23));
+        const float s01 = act ? e0 + e1 : 0.f, s23 = act ? e2 + e3 : 0.f;
+        const float sa = half_sum((a01 ? s01 : 0.f) + (a23 ? s23 : 0.f));
+        const float sb = half_sum((a01 ? 0.f : s01) + (a23 ? 0.f : s23));
+        const float la = ma + __builtin_amdgcn_logf(sa) * LN2, lb = mb + __builtin_amdgcn_logf(sb) * LN2;
+        const float l01 = a01 ? la : lb, l23 = a23 ? la : lb;
+        if (act) strip[wv][(2 * i + half) * 25 + j] = f4{t.x - l01, t.y - l01, t.z - l23, t.w - l23};
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const size_t f0 = w * 100, nf = npairs * 25;
+    if (f0 + lane < nf) store4<SP>(out + f0 + lane, strip[wv][lane]);
+    if (lane < 36 && f0 + 64 + lane < nf) store4<SP>(out + f0 + 64 + lane, strip[wv][64 + lane]);
+}
 template <bool LNT, int SP>
 __global__ void __launch_bounds__(256) k_copy1(const f4* __restrict__ a, f4* __restrict__ b, size_t n) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -123,6 +165,12 @@ int main() {
         LSM(false, ST_NT, "log-softmax regs, plain loads, nt stores")
         LSM(false, ST_SC1, "log-softmax regs, plain loads, sc1 stores")
         LSM(false, ST_PLAIN, "log-softmax regs, plain loads, plain stores")
+#define LIN(LNT, SP, label) run(label, [&] { k_lsm_rp_lin<LNT, SP><<<(unsigned)((npairs / 2 + 7) / 8), 256>>>(a, b, npairs); }, bytes);
+        LIN(true, ST_NT, "log-softmax regs, stores LINEAR through LDS, nt / nt")
+        LIN(true, ST_PLAIN, "log-softmax regs, stores LINEAR through LDS, nt / plain")
+        LIN(true, ST_SC1, "log-softmax regs, stores LINEAR through LDS, nt / sc1")
+        LIN(true, ST_SC1NT, "log-softmax regs, stores LINEAR through LDS, nt / sc1 nt")
+        LSM(true, ST_NT, "log-softmax regs, nt loads, nt stores (shipped) again")
         CPY(false, ST_PLAIN, "copy 1 float4 / thread, plain / plain")
         CPY(true, ST_NT, "copy 1 float4 / thread, nt / nt")
         CPY(true, ST_SC1, "copy 1 float4 / thread, nt / sc1")
@@ -149,6 +197,8 @@ int main() {
             printf("\n");
         };
 #define CHK(SP, label) one([&] { k_lsm_rp<2, true, SP><<<grid, 256>>>(a, b, npairs); }, got); cmp(label);
+        one([&] { k_lsm_rp_lin<true, ST_NT><<<grid, 256>>>(a, b, npairs); }, got); cmp("linear nt");
+        one([&] { k_lsm_rp_lin<true, ST_SC1><<<grid, 256>>>(a, b, npairs); }, got); cmp("linear sc1");
         CHK(ST_NT, "nt") CHK(ST_SC1, "sc1") CHK(ST_SC0SC1, "sc0 sc1") CHK(ST_SC1NT, "sc1 nt") CHK(ST_SC0SC1NT, "sc0 sc1 nt") CHK(ST_SC0, "sc0")
         one([&] { k_copy1<true, ST_SC1><<<(unsigned)((n + 255) / 256), 256>>>(a, b, n); }, got);
         printf("  copy nt / sc1 against its input: %s\n", memcmp(got.data(), h.data(), bytes) ? "DIFFERENT" : "same");

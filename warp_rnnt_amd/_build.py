@@ -75,6 +75,12 @@ VARIANTS = {
     "ab": ["-DRNNT_AB_KNOBS"],
     # A/B: the dense gather's pair stores left dirty in L2 (rounds 1-5) instead of written through (sc1)
     "gather_plain_stores": ["-DRNNT_GATHER_STORE_SC1=0"],
+    # A/B: the register log-softmax kernel's row maxima by fmaxf() on DPP results (rounds 3-5) instead of v_max_f32_dpp
+    "lsm_regs_c_max": ["-DRNNT_LSM_REGS_ASM_MAX=0"],
+    # A/B: ... its results stored straight from the registers (400-byte segments at V=50) instead of in address order via LDS
+    "lsm_regs_direct": ["-DRNNT_LSM_REGS_LINEAR=0"],
+    "lsm_regs_r05": ["-DRNNT_LSM_REGS_LINEAR=0", "-DRNNT_LSM_REGS_ASM_MAX=0"],
+    "lsm_regs_nt_stores": ["-DRNNT_LSM_REGS_STORE_WT=0"],
     # timing probes of the fused logits -> pairs kernel's stores (WRONG results: tools/fused_store_probe.py only)
     "probe_hot_pairs": ["-DRNNT_PROBE_HOT_PAIRS"],
     "probe_linear_pairs": ["-DRNNT_PROBE_LINEAR_PAIRS"],

@@ -577,7 +577,81 @@ __device__ __forceinline__ float half_sum32(float v) {
     v += lsm_dpp<0xB1>(v); v += lsm_dpp<0x4E>(v); v += lsm_dpp<0x124>(v); v += lsm_dpp<0x128>(v);
     return v + lsm_swz16(v);
 }
-constexpr int RG_UN = 2;          // groups per half and wave, loads first (1: 500 us, 2: 462-484, 4: 482-498)
+// The KR row maxima of a group in ONE hand-written statement (round 6).  fmaxf() on a DPP result compiles to three
+// instructions per butterfly step -- v_mov_b32_dpp, a v_max x,x that quiets a possible signalling NaN, the v_max -- where
+// one v_max_f32_dpp does the work; with two rows per group that is 48 of the kernel's 311 vector instructions per wave, and
+// the kernel sits AT the vector-issue bound (311 x 900 k waves / (1024 SIMDs x 0.6 G instructions/s) = 456 us of its 462).
+// The KR chains are interleaved, so a step's result is two wait states old when the next step reads it through DPP
+// (KR = 1, 2: topped up with s_nop); the leading s_nop 1 covers the compiler's instruction that produced the inputs
+// (_isa_check.py walks the generated ISA for exactly these).  v_max_f32 returns the other operand for a quiet NaN as
+// fmaxf does; a signalling NaN makes the row's maximum NaN and with it the row, which it would be anyway.
+// The results leave through a per-wave LDS strip in ADDRESS order (round 6).  A group's segment (V = 50: 400 bytes) starts
+// and ends inside 64-byte granules, and what that costs is the STORES: a copy whose stores sit 16 or 32 bytes off the
+// 64-byte grid loses 5-19 %, one whose loads do loses nothing (tools/ubench/copy_shape.hip).  Two ds_write_b128 + two
+// ds_read_b128 per lane turn the wave's four segments into one store instruction of 1024 contiguous bytes and one of the
+// rest, all whole granules: the V=50 micro-benchmark 465 -> 457-460 us, same bits (tools/ubench/lsm_store_policy.hip).
+// In the step (bench.py, c4, interleaved processes, profiles/r06_lsm_regs_ab.txt): 0.7997 -> 0.7924 ms on one box, 0.8418 ->
+// 0.8323 on another; and with the stores then also written through AND streaming (sc1 nt: whole granules that nothing
+// else will add to -- the case in which write-through pays) 0.8323 -> 0.8267.  Blocks of four groups per
+// half (RNNT_LSM_REGS_UN=4) lose 20 us.
+#ifndef RNNT_LSM_REGS_LINEAR
+#define RNNT_LSM_REGS_LINEAR 1
+#endif
+#ifndef RNNT_LSM_REGS_STORE_WT
+#define RNNT_LSM_REGS_STORE_WT RNNT_LSM_REGS_LINEAR
+#endif
+#ifndef RNNT_LSM_REGS_ASM_MAX
+#define RNNT_LSM_REGS_ASM_MAX 1
+#endif
+#define RNNT_DPPMAX(R, CTRL) "v_max_f32_dpp " R ", " R ", " R " " CTRL " row_mask:0xf bank_mask:0xf\n\t"
+#define RNNT_DPPMAX_STEPS(BODY, GAP)                                                                     \
+    "s_nop 1\n\t" BODY("quad_perm:[1,0,3,2]") GAP BODY("quad_perm:[2,3,0,1]") GAP BODY("row_ror:4") GAP BODY("row_ror:8")
+template <int KR> __device__ __forceinline__ void half_max32_rows(float (&M)[KR]) {
+    static_assert(KR >= 1 && KR <= 4, "one to four rows per group");
+#if RNNT_LSM_REGS_ASM_MAX
+    float t0, t1, t2, t3;
+    if constexpr (KR == 1) {
+#define RNNT_B1(C) RNNT_DPPMAX("%0", C)
+        asm volatile(RNNT_DPPMAX_STEPS(RNNT_B1, "s_nop 1\n\t")
+                     "ds_swizzle_b32 %1, %0 offset:swizzle(SWAP,16)\n\ts_waitcnt lgkmcnt(0)\n\tv_max_f32 %0, %0, %1"
+                     : "+v"(M[0]), "=&v"(t0));
+#undef RNNT_B1
+    } else if constexpr (KR == 2) {
+#define RNNT_B2(C) RNNT_DPPMAX("%0", C) RNNT_DPPMAX("%1", C)
+        asm volatile(RNNT_DPPMAX_STEPS(RNNT_B2, "s_nop 0\n\t")
+                     "ds_swizzle_b32 %2, %0 offset:swizzle(SWAP,16)\n\tds_swizzle_b32 %3, %1 offset:swizzle(SWAP,16)\n\t"
+                     "s_waitcnt lgkmcnt(0)\n\tv_max_f32 %0, %0, %2\n\tv_max_f32 %1, %1, %3"
+                     : "+v"(M[0]), "+v"(M[1]), "=&v"(t0), "=&v"(t1));
+#undef RNNT_B2
+    } else if constexpr (KR == 3) {
+#define RNNT_B3(C) RNNT_DPPMAX("%0", C) RNNT_DPPMAX("%1", C) RNNT_DPPMAX("%2", C)
+        asm volatile(RNNT_DPPMAX_STEPS(RNNT_B3, "")
+                     "ds_swizzle_b32 %3, %0 offset:swizzle(SWAP,16)\n\tds_swizzle_b32 %4, %1 offset:swizzle(SWAP,16)\n\t"
+                     "ds_swizzle_b32 %5, %2 offset:swizzle(SWAP,16)\n\t"
+                     "s_waitcnt lgkmcnt(0)\n\tv_max_f32 %0, %0, %3\n\tv_max_f32 %1, %1, %4\n\tv_max_f32 %2, %2, %5"
+                     : "+v"(M[0]), "+v"(M[1]), "+v"(M[2]), "=&v"(t0), "=&v"(t1), "=&v"(t2));
+#undef RNNT_B3
+    } else {
+#define RNNT_B4(C) RNNT_DPPMAX("%0", C) RNNT_DPPMAX("%1", C) RNNT_DPPMAX("%2", C) RNNT_DPPMAX("%3", C)
+        asm volatile(RNNT_DPPMAX_STEPS(RNNT_B4, "")
+                     "ds_swizzle_b32 %4, %0 offset:swizzle(SWAP,16)\n\tds_swizzle_b32 %5, %1 offset:swizzle(SWAP,16)\n\t"
+                     "ds_swizzle_b32 %6, %2 offset:swizzle(SWAP,16)\n\tds_swizzle_b32 %7, %3 offset:swizzle(SWAP,16)\n\t"
+                     "s_waitcnt lgkmcnt(0)\n\tv_max_f32 %0, %0, %4\n\tv_max_f32 %1, %1, %5\n\tv_max_f32 %2, %2, %6\n\t"
+                     "v_max_f32 %3, %3, %7"
+                     : "+v"(M[0]), "+v"(M[1]), "+v"(M[2]), "+v"(M[3]), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3));
+#undef RNNT_B4
+    }
+#else
+#pragma unroll
+    for (int r = 0; r < KR; ++r) M[r] = half_max32(M[r]);
+#endif
+}
+#undef RNNT_DPPMAX_STEPS
+#undef RNNT_DPPMAX
+#ifndef RNNT_LSM_REGS_UN
+#define RNNT_LSM_REGS_UN 2
+#endif
+constexpr int RG_UN = RNNT_LSM_REGS_UN;   // groups per half and wave, loads first (1: 500 us, 2: 462-484, 4: 482-498)
 
 // NT: bit 0 = non-temporal loads, bit 1 = non-temporal stores (both: 462 us for the c4 tensor, neither: 484)
 #ifndef RNNT_LSM_REGS_NT
@@ -589,6 +663,10 @@ __global__ void __launch_bounds__(256) k_lsm_regs(const float* __restrict__ x, f
     const int lane = threadIdx.x & 63, j = lane & 31, half = lane >> 5;
     const int g4 = (KR * V) >> 2;                  // float4 per group
     const bool act = j < g4;
+#if RNNT_LSM_REGS_LINEAR
+    __shared__ lsm_f4 strip[4][64 * RG_UN];        // per wave: its 2 * RG_UN groups of <= 32 float4 in address order
+    const int wv = threadIdx.x >> 6;
+#endif
     // xcd: the eight XCDs (blockIdx mod 8; the grid is a multiple of 8) each stream a contiguous eighth of the groups
     const unsigned wg = xcd ? (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3) : blockIdx.x;
     const int64_t w = (int64_t)wg * 4 + (threadIdx.x >> 6);
@@ -608,7 +686,7 @@ __global__ void __launch_bounds__(256) k_lsm_regs(const float* __restrict__ x, f
     }
 #pragma unroll
     for (int i = 0; i < RG_UN; ++i) {
-        const int64_t g = (w * RG_UN + i) * 2 + half;
+        [[maybe_unused]] const int64_t g = (w * RG_UN + i) * 2 + half;
         const lsm_f4 t = v[i];
         const float ninf = -__builtin_inff();
         // maxima of the lane's two parts, then of every row of the group over the half
@@ -617,8 +695,8 @@ __global__ void __launch_bounds__(256) k_lsm_regs(const float* __restrict__ x, f
         const float mf = fmaxf(fmaxf(a0, a1), fmaxf(a2, a3)), ms = fmaxf(b1, fmaxf(b2, b3));
         float M[KR];
 #pragma unroll
-        for (int r = 0; r < KR; ++r)
-            M[r] = half_max32(act ? (r0 == r ? mf : (r0 + 1 == r ? ms : ninf)) : ninf);
+        for (int r = 0; r < KR; ++r) M[r] = act ? (r0 == r ? mf : (r0 + 1 == r ? ms : ninf)) : ninf;
+        half_max32_rows<KR>(M);
         float m_first = M[0], m_second = M[KR - 1];
 #pragma unroll
         for (int r = 1; r < KR; ++r) m_first = r0 == r ? M[r] : m_first;
@@ -647,8 +725,31 @@ __global__ void __launch_bounds__(256) k_lsm_regs(const float* __restrict__ x, f
                                   ns > 1 ? (t.y - m_first) - l_first : (t.y - m_second) - l_second,
                                   ns > 2 ? (t.z - m_first) - l_first : (t.z - m_second) - l_second,
                                   ns > 3 ? (t.w - m_first) - l_first : (t.w - m_second) - l_second};
+#if RNNT_LSM_REGS_LINEAR
+        if (act) strip[wv][(2 * i + half) * g4 + j] = res;
+#else
         if (act && g < ngroups) { if (NT & 2) __builtin_nontemporal_store(res, xout + g * g4 + j); else xout[g * g4 + j] = res; }
+#endif
     }
+#if RNNT_LSM_REGS_LINEAR
+    // the wave's 2 * RG_UN groups are 64 * g4 contiguous bytes: out of the strip in address order, one store instruction of
+    // 1024 bytes and one of the rest -- every instruction whole 64-byte granules (the strip is the wave's own: no barrier)
+    wave_sync_lds();
+    const int64_t f0 = w * (2 * RG_UN) * g4, nf = ngroups * g4;
+    const int nw = 2 * RG_UN * g4;                  // float4 of this wave (<= 64 * RG_UN)
+#pragma unroll
+    for (int k = 0; k < RG_UN; ++k) {
+        const int f = k * 64 + lane;
+        if (f < nw && f0 + f < nf) {
+            const lsm_f4 r = strip[wv][f];
+#if RNNT_LSM_REGS_STORE_WT      // written through and streaming (the s_nop: _isa_check.py, second rule)
+            asm volatile("global_store_dwordx4 %0, %1, off sc1 nt\n\ts_nop 1" ::"v"(xout + f0 + f), "v"(r) : "memory");
+#else
+            if (NT & 2) __builtin_nontemporal_store(r, xout + f0 + f); else xout[f0 + f] = r;
+#endif
+        }
+    }
+#endif
 }
 
 // ---------------------------------------------------------------------------
