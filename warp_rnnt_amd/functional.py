@@ -9,7 +9,7 @@ dtype, device, autograd history) but has not computed them.
     logits, 4V+8 B/cell; backward ``rnnt_amd_logits_backward``: one more read and the write of d/d logits, 8V+8 B/cell)
     -- the log-probabilities and their dense gradient never exist in HBM.  Same bits as
     ``warp_rnnt_amd.fused.rnnt_loss_from_logits`` (it IS that path), half the time of the materialised chain at
-    N=16, T=1500, U=300, V=50 (forward 0.36-0.40 vs 0.81 ms, training step 0.83 vs 1.73).
+    N=16, T=1500, U=300, V=50 (forward 0.36-0.41 vs 0.80 ms, training step 0.83 vs 1.75).
   * ANY other consumer -- an arithmetic op, indexing, ``.cpu()``, printing, ``gather=False``, ``compact=True``, a leaf
     handle that itself requires grad -- materialises the log-probabilities once, through the library's streaming
     log-softmax kernel (k_lsm_regs / k_lsm_small / k_lsm_large), and carries on with an ordinary tensor; backward through
