@@ -142,7 +142,7 @@ k_tile(const float* __restrict__ src, const int* __restrict__ labels, float2* __
 // The shipped structure with the pair stores as buffer stores carrying cache-policy bits (gfx940+: 1 = sc0, 2 = nt, 16 = sc1;
 // sc0 sc1 = system scope: written through, nothing left dirty in L2) -- do dirty lines on their way out of L2 hold back the
 // fills of the read stream (profiles/r06_gather_store_pmc.csv), and does writing THROUGH avoid it?
-template <int TT, int TD, int ORDER, int AUX>
+template <int TT, int TD, int ORDER, int AUX, int PITCH = 0>
 __global__ void __launch_bounds__(256)
 k_tile_aux(const float* __restrict__ src, const int* __restrict__ labels, float2* __restrict__ ws2, int N, int T, int U, int V,
            int blank, int tiles_t, int tiles_u, unsigned out_bytes) {
@@ -178,7 +178,8 @@ k_tile_aux(const float* __restrict__ src, const int* __restrict__ labels, float2
             if (t < T && u < U) {
                 int r = t + u;
                 r = r >= T ? r % T : r;
-                const size_t at = nbase + (size_t)r * U + u;
+                const int Up = PITCH > 0 ? (U + PITCH - 1) / PITCH * PITCH : U;       // PITCH > 0: rows padded to PITCH pairs
+                const size_t at = ((size_t)id.n * T + r) * Up + u;
                 const float2 pr = tile[tl][ul];
                 i2v q; q.x = __builtin_bit_cast(int, pr.x); q.y = __builtin_bit_cast(int, pr.y);
                 __builtin_amdgcn_raw_buffer_store_b64(q, rs, (int)(at * 8), 0, AUX);
@@ -329,6 +330,9 @@ int main(int argc, char** argv) {
     for (int round = 0; round < 2; ++round) {      // (twice: run-to-run drift on a box is a few us)
         TILE(32, 32, 0, false, false, ref, false, "32x32 linear (shipped shape, forward walk)")
         TILE(32, 32, 1, false, false, out, true, "32x32 linear reversed (shipped)")
+        TILE(32, 32, 0, false, false, out, true, "32x32 linear forward, into the other buffer")
+        TILE(32, 32, 1, false, false, ref, false, "32x32 linear reversed, into the first buffer")
+        TILE(32, 32, 0, false, false, ref, false, "32x32 linear forward, into the first buffer again")
         TILE(32, 32, 0, true, false, out, false, "32x32 linear, stores into a hot 64 KB buffer (no DRAM writes)")
         TILE(32, 32, 2, false, false, out, true, "32x32 strips per XCD")
         TILE(32, 32, 3, false, false, out, true, "32x32 strips per XCD, reversed")
@@ -353,6 +357,20 @@ int main(int argc, char** argv) {
         TILEA(1, "32x32 reversed, stores sc0")
         TILEA(19, "32x32 reversed, stores sc0 sc1 nt")
         TILEA(2, "32x32 reversed, stores nt")
+#define TILEAP(AUX, PITCH, label)                                                                                      \
+    {                                                                                                                 \
+        const int tiles_t = (T + 31) / 32, tiles_u = (U + 31) / 32;                                                   \
+        const unsigned grid = grid_of(1, N, tiles_t, tiles_u);                                                        \
+        run(label, [&] { k_tile_aux<32, 32, 1, AUX, PITCH><<<grid, 256>>>(src, labels, out, N, T, U, V, 0, tiles_t, tiles_u, (unsigned)(cells * 10)); }); \
+        CHECK(hipMemset(out, 0xff, cells * 8));                                                                       \
+    }
+        // written through AND every run on the 64-byte grid (rows padded to 8 / 16 pairs): half of the shipped plane's rows
+        // start 32 bytes off it (U = 300: 2400-byte rows)
+        TILEAP(16, 8, "32x32 reversed, stores sc1, rows padded to 64 bytes (U 300 -> 304)")
+        TILEAP(16, 16, "32x32 reversed, stores sc1, rows padded to 128 bytes (U 300 -> 304)")
+        TILEAP(18, 8, "32x32 reversed, stores sc1 nt, rows padded to 64 bytes")
+        TILEAP(0, 8, "32x32 reversed, default policy, rows padded to 64 bytes")
+        TILEA(18, "32x32 reversed, stores sc1 nt")
 #define TILEP(TT, TD, ORDER, PITCH, label)                                                                             \
     {                                                                                                                 \
         const int tiles_t = (T + TT - 1) / TT, tiles_u = (U + TD - 1) / TD;                                           \
