@@ -130,6 +130,33 @@ def test_results_do_not_depend_on_timing_or_workspace_contents():
     torch.cuda.synchronize()
 
 
+@pytest.mark.parametrize("N,T,U", [(4, 600, 300), (3, 1100, 150), (5, 333, 129), (6, 200, 64), (3, 1500, 70)])
+@pytest.mark.parametrize("poison", [float("nan"), float("inf"), -float("inf"), 3.0e38])
+def test_cells_outside_an_utterance_never_reach_a_result(N, T, U, poison):
+    """Ragged batch with every pair OUTSIDE an utterance's own (T_n, U_n) lattice poisoned.  The hand-written blocks run
+    unpredicated: lanes compute on before their first frame (head blocks), behind their last (since round 6 the blocks
+    lanes finish in run the steady-state code too, csrc/lattice_wd_body.h: RNNT_WD_FAST_TAIL) and in columns beyond U_n --
+    on whatever the planes hold there.  None of it may reach a cost, a gradient, or the forward/backward check: the same
+    bits as the single-workgroup kernel on the clean batch, from every kernel and both block sizes' default route."""
+    logits, labels, xn, yn = make_case(77 + N + T + U, N, T, U, 5, ragged=True)
+    xn[0], yn[0] = T, U - 1                                     # one full-size utterance keeps the launch bounds
+    clean = _pairs(logits, labels)
+    dirty = clean.copy()
+    for n in range(N):
+        dirty[n, xn[n]:, :, :] = poison
+        dirty[n, :, yn[n] + 1:, :] = poison
+        dirty[n, :, yn[n], 1] = poison                         # (the label slot of the last column: no label there)
+    txn, tyn = torch.tensor(xn, device=DEV), torch.tensor(yn, device=DEV)
+    c0, g0 = _run(torch.tensor(clean, device=DEV), txn, tyn, "ws", lam=0.01)
+    lp2 = torch.tensor(dirty, device=DEV)
+    for kernel in ("wd", "wl", "ws"):
+        c, g = _run(lp2, txn, tyn, kernel, lam=0.01)
+        assert torch.isfinite(c).all(), (kernel, c)
+        assert torch.equal(c, c0), kernel
+        # gradients: identical on every cell -- the utterances' own lattices, and the zeros outside them
+        assert torch.equal(g, g0), kernel
+
+
 def test_lost_hand_over_is_redone_by_the_single_workgroup_kernel():
     """`short_spin` build: a hand-over wait gives up at the first poll, so every column block that catches up with its
     neighbour runs on stale boundary values, flags its sweep, and the kernel launched behind redoes it.  Same bits."""

@@ -75,6 +75,9 @@ VARIANTS = {
     "ab": ["-DRNNT_AB_KNOBS"],
     # A/B: the dense gather's pair stores left dirty in L2 (rounds 1-5) instead of written through (sc1)
     "gather_plain_stores": ["-DRNNT_GATHER_STORE_SC1=0"],
+    # A/B: the blocks of k_lattice_wd / k_lattice_wl in which lanes finish in the predicated C++ form (rounds 4-6) instead of
+    # the hand-written steady-state code
+    "wd_masked_tail": ["-DRNNT_WD_FAST_TAIL=0"],
     # A/B: the register log-softmax kernel's row maxima by fmaxf() on DPP results (rounds 3-5) instead of v_max_f32_dpp
     "lsm_regs_c_max": ["-DRNNT_LSM_REGS_ASM_MAX=0"],
     # A/B: ... its results stored straight from the registers (400-byte segments at V=50) instead of in address order via LDS

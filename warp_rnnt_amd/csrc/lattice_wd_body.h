@@ -33,6 +33,9 @@ constexpr int SPIN_LIMIT = RNNT_WD_SPIN_LIMIT;   // polls before a hand-over is 
 #ifndef RNNT_WD_LAG
 #define RNNT_WD_LAG 1
 #endif
+#ifndef RNNT_WD_FAST_TAIL
+#define RNNT_WD_FAST_TAIL 1    // the blocks lanes finish in run the hand-written steady-state code (sweep(): full_end)
+#endif
 #ifndef RNNT_WL_PAD
 #define RNNT_WL_PAD 1          // two column blocks: eight waves, the compute waves alone on their SIMDs (k_lattice_wl)
 #endif
@@ -327,6 +330,17 @@ __device__ __forceinline__ void sweep(const LatticeArgs& a, const Item it, const
             lb = lo;
             // (a lattice so short that lanes start and finish in the same blocks: everything in the general variant)
             head_end = fb0 < fb1 ? fb0 : lo; full_end = fb0 < fb1 ? fb1 : lo; tail_end = hi;
+#if RNNT_WD_FAST_TAIL
+            // The blocks lanes FINISH in (none starts: they lie behind fb0) run the steady-state code as well.  What a lane
+            // computes behind its last frame reaches no result: the storer predicates the stores of every block outside
+            // [sfb0, sfb1) per lane; its right neighbour's last live cell (row T_n - 1, one diagonal later) reads the lane's
+            // own LAST LIVE value, and so does the next column block's lane 0 from the boundary column (column c is live on
+            // diagonals [c, c + T_n - 1], column c + 1 reads it on [c, c + T_n - 1]).  The one thing the general variant's
+            // per-lane freeze is needed for is alpha's log-likelihood -- Y of the lane that owns column U_n - 1, read behind
+            // the loop -- and that lane finishes on the sweep's very last diagonal: the last block of the last column block
+            // of an alpha sweep stays in the general variant, nothing else.
+            if (fb0 < fb1) full_end = max(fb1, (!BETA && idx == nwa - 1) ? hi - 1 : hi);
+#endif
         }
         int slot = 0;                                          // LDS slot of block lb's pairs (block lo = slot 0)
         const unsigned pairs0 = (unsigned)(size_t)(__attribute__((address_space(3))) const char*)&sm.pairs[0][0][pos];
