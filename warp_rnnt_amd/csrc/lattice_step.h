@@ -181,8 +181,10 @@ __device__ __forceinline__ void compute_block(const f32x2 (&cur)[K], const float
 // Two bodies.  The predicated block (MASKED: lanes start or finish inside it -- a few blocks at either end of a column
 // block's life) is C++.  The block every lane is live in -- nine tenths of a long sweep, and the sweep runs at the pace of
 // its slowest wave -- is written instruction by instruction (round 5), because a lone wave issues one instruction every
-// ~5.8 cycles whatever it is, so the sweep's time IS that wave's instruction count, and the compiler's version carried
-// three to four instructions per diagonal that do nothing for the result:
+// ~5.8 cycles whatever it is (priced link by link in round 6, tools/ubench/step_chain.hip: 4.7 - 5.0 cycles for a dependent
+// vector instruction, 4.0 for an independent one or an s_nop, 8 for v_exp_f32 / v_log_f32, nothing extra for DPP -- there
+// are no latency shadows to hide work in), so the sweep's time IS that wave's instruction count, and the compiler's version
+// carried three to four instructions per diagonal that do nothing for the result:
 //   * fmaxf(a, b) is up to three v_max_f32: the compiler quiets signalling NaNs first (v_max x, x, x) on every operand it
 //     cannot prove to be the result of an arithmetic instruction -- the DPP shift's output always -- which made the
 //     alpha sweep two instructions per diagonal longer than the beta sweep.  Nothing on the chain produces a signalling

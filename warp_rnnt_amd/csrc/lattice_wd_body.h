@@ -4,8 +4,9 @@
 //   RNNT_WD_KK   diagonals per block = per interval = per s_barrier
 // Blocks of 16 diagonals halve what a block costs besides its diagonals (the barrier, the wait in front of it, the loop
 // around it, the loader's and the storer's fixed parts) and pay with twice the predicated work at either end of a column
-// block's life and twice the LDS.  The shipped default is 8 everywhere; 16 is opt-in (lattice_wd.hip: wd_block_diagonals
-// says why).  No include guard: included once per instantiation.  Read lattice_wd.hip's header first.
+// block's life and twice the LDS, and a hand-over distance of five intervals that grows with them.  Shipped: 16 from launch
+// bound T >= 1024 on, 8 below (lattice_wd.hip: wd_block_diagonals has the history).  No include guard: included once per
+// instantiation.  Read lattice_wd.hip's header first.
 namespace RNNT_WD_NS {
 
 constexpr int K = RNNT_WD_KK;          // diagonals per block = per interval = per s_barrier (8 or 16; lattice_ws.hip: 8)
