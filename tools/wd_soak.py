@@ -12,13 +12,14 @@ the processes keep the GPU saturated; the redo flags (bit 1 = a hand-over wait t
 the sweep: allowed, counted) are accumulated the same way.  A case that shows a mismatch is re-run launch by launch with
 a description of what differs.
 
-Shapes (N, T, U; r = ragged lengths) -- the six-shape set:
+Shapes (N, T, U; r = ragged lengths) -- the six-shape set, and a seventh since the end of round 6:
     16,1500,300     c4: five column blocks, k_lattice_wd with rings, blocks of 16 diagonals (RNNT_WD_K16_FROM_T=1000000: of 8)
     12,700,180,r    three column blocks, k_lattice_wd with rings
     16,400,100      two column blocks, k_lattice_wl
     32,250,100,r    two column blocks, k_lattice_wl, ragged
     32,500,200      four column blocks on a short batch: k_lattice_wl in its large-LDS form
     16,150,40       c2's lattice: one column block, k_lattice_wd as a plain launch
+    12,1300,120,r   two column blocks on a long sweep: k_lattice_wd with rings (from T >= 1200; csrc/lattice.hip), ragged
 WD_SOAK_SHAPES="N,T,U[,r] ..." overrides.
 
     python tools/wd_soak.py --seconds 60 [--procs 6]      (--procs: that many copies at once on the one GPU)
@@ -33,7 +34,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 SHAPES = ((16, 1500, 300, False), (12, 700, 180, True), (16, 400, 100, False), (32, 250, 100, True), (32, 500, 200, False),
-          (16, 150, 40, False))
+          (16, 150, 40, False), (12, 1300, 120, True))
 BATCH = 40          # launches between two read-backs of the device-side counters
 
 
