@@ -29,7 +29,7 @@ def test_random_cases_against_the_oracle(kernel, seed):
 @pytest.mark.parametrize("name,env_extra", [("default", {}), ("wl", {"RNNT_DEBUG_LATTICE_KERNEL": "wl"}),
                                             ("k8", {"RNNT_WD_K16_FROM_T": "1000000"})])
 def test_six_processes_on_one_gpu_get_the_reference_bits_every_launch(name, env_extra):
-    """tools/wd_soak.py: six processes launch the loss entry back to back on the six-shape set at the same time (45 s each
+    """tools/wd_soak.py: six processes launch the loss entry back to back on the soak's shape set at the same time (45 s each
     leg) and compare every launch -- costs, gradients, alpha and beta planes -- bit for bit with a reference computed once
     by the OTHER kernel (k_lattice_ws: compiler-scheduled, no in-place reloads, no hand-over through L2).  This is the load
     that found what no single-process test could: the hand-written lattice blocks with reloads left in flight across the
