@@ -88,6 +88,7 @@ hipError_t launch_lattice_ws(hipStream_t stream, const LatticeArgs& a, int N);
 // padded or 64-bit compact; any U); needs a.redo, a.queue and -- for U > 64 -- a.mail of wd_mail_bytes(N,T,U) bytes;
 // hipErrorNotSupported when they are missing.
 hipError_t launch_lattice_wd(hipStream_t stream, const LatticeArgs& a, int N);
+int device_cus(hipStream_t stream);   // compute units of the stream's device (csrc/lattice.hip)
 size_t wd_mail_bytes(int N, int T, int U);
 // ... and its single-workgroup form (lattice_wd.hip: k_lattice_wl): all column blocks of a sweep as waves of one
 // workgroup, boundary columns through LDS; needs nothing but the planes (no flags, no rings), padded or compact with

@@ -61,7 +61,7 @@ __global__ void __launch_bounds__(MAXW * WAVE) k_lattice(const LatticeArgs a) {
 
 // compute units of the stream's device (one query per process and device; 256 on MI355X): the kernels with one
 // workgroup per column block want CUs of their own for them
-static int device_cus(hipStream_t stream) {
+int device_cus(hipStream_t stream) {
     static std::atomic<int> cached[64];
     int dev = 0;
     // the device that owns the stream the kernels go to (not necessarily the current one)

@@ -74,10 +74,16 @@ namespace rnnt {
 // the reload check is part of the build, the end-of-block wait holds the refilled registers as operands, and the soak
 // record (profiles/r06_wd_soak.txt: millions of launches under three and six processes, every launch compared with
 // k_lattice_ws's bits) has no mismatch and no lost hand-over on either block size.
-// RNNT_WD_K16_FROM_T=<T> moves the threshold (1: blocks of 16 everywhere; a huge T: blocks of 8 everywhere; same bits).
-static int wd_block_diagonals(int T) {
-    static const int from_t = getenv("RNNT_WD_K16_FROM_T") ? atoi(getenv("RNNT_WD_K16_FROM_T")) : 1024;
-    return T >= from_t ? 16 : 8;
+// ONE column block per sweep (U <= 64) hands nothing over, so the longer blocks cost no hand-over distance: 16 from T >= 320
+// while every workgroup has a CU of its own (end of round 6, profiles/r06_k16_threshold.txt, 8 / 16: N=16, U=64: T=350
+// 22.2 / 21.5, T=500 28.5 / 27.5, T=700 36.8 / 34.6, T=1100 53.2 / 49.4; T=150, U=40 12.6 / 12.9 and N=256, T=500 36.4 / 37.3
+// stay with 8); several column blocks: T=640, U=300 63.3 / 64.7, T=900 76.3 / 75.3, T=1024 81.9 / 80.6 -- 1024 stays.
+// RNNT_WD_K16_FROM_T=<T> replaces both thresholds (1: blocks of 16 everywhere; a huge T: blocks of 8 everywhere; same bits).
+static int wd_block_diagonals(hipStream_t stream, int T, int U, int N) {
+    static const int from_t = getenv("RNNT_WD_K16_FROM_T") ? atoi(getenv("RNNT_WD_K16_FROM_T")) : -1;
+    if (from_t >= 0) return T >= from_t ? 16 : 8;
+    if (U <= WAVE && T >= 320 && (long long)2 * N <= (long long)device_cus(stream)) return 16;
+    return T >= 1024 ? 16 : 8;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -147,9 +153,9 @@ size_t wd_mail_bytes(int N, int T, int U) {
 }
 
 // bytes of rings a launch on `a` uses (by the block size it will run with)
-static size_t wd_ring_bytes(const LatticeArgs& a, int N) {
+static size_t wd_ring_bytes(hipStream_t stream, const LatticeArgs& a, int N) {
     const int nA = (a.U + WAVE - 1) / WAVE;
-    const size_t pitch = wd_block_diagonals(a.T) == 16 ? wd16::ring_pitch(a.T, a.U) : wd8::ring_pitch(a.T, a.U);
+    const size_t pitch = wd_block_diagonals(stream, a.T, a.U, N) == 16 ? wd16::ring_pitch(a.T, a.U) : wd8::ring_pitch(a.T, a.U);
     return nA < 2 ? 0 : (size_t)2 * N * (nA - 1) * pitch * sizeof(wd8::u64);
 }
 
@@ -159,7 +165,7 @@ bool wd_ring_prep(hipStream_t stream, const LatticeArgs& a, int N, RingPrep* pre
     if (nA > 1 && !a.mail) return false;
     unsigned* counter = launch_counter_address(stream);
     if (!counter) return false;
-    const size_t ring_bytes = wd_ring_bytes(a, N);
+    const size_t ring_bytes = wd_ring_bytes(stream, a, N);
     *prep = RingPrep{a.redo, 2 * N + 1, counter, reinterpret_cast<uint4*>(a.mail), ring_bytes / 16};
     return true;
 }
@@ -181,7 +187,7 @@ hipError_t launch_lattice_wd(hipStream_t stream, const LatticeArgs& a0, int N) {
 #endif
     if (!lone && (!a0.redo || !a0.queue || (nA > 1 && !a0.mail))) return hipErrorNotSupported;
     if ((long long)2 * N * nA >= (1ll << 31)) return hipErrorNotSupported;
-    const bool k16 = wd_block_diagonals(a0.T) == 16;
+    const bool k16 = wd_block_diagonals(stream, a0.T, a0.U, N) == 16;
     LatticeArgs a = a0;
     if (lone) {
         a.queue = nullptr;
@@ -189,7 +195,7 @@ hipError_t launch_lattice_wd(hipStream_t stream, const LatticeArgs& a0, int N) {
     } else {
         a.epoch = next_launch_epoch();
         if (!a.prepared) {     // (prepared: the producer of this call's pair plane did it at the tail of its own launch)
-            const hipError_t e = launch_ring_prepare(stream, a.redo, 2 * N + 1, a.mail, wd_ring_bytes(a, N));
+            const hipError_t e = launch_ring_prepare(stream, a.redo, 2 * N + 1, a.mail, wd_ring_bytes(stream, a, N));
             if (e != hipSuccess) return e;
         }
     }
