@@ -5,7 +5,8 @@
 // Blocks of 16 diagonals halve what a block costs besides its diagonals (the barrier, the wait in front of it, the loop
 // around it, the loader's and the storer's fixed parts) and pay with twice the predicated work at either end of a column
 // block's life and twice the LDS, and a hand-over distance of five intervals that grows with them.  Shipped: 16 from launch
-// bound T >= 1024 on, 8 below (lattice_wd.hip: wd_block_diagonals has the history).  No include guard: included once per
+// bound T >= 1024 on -- from T >= 320 where one column block is the whole lattice --, 8 below (lattice_wd.hip:
+// wd_block_diagonals has the history).  No include guard: included once per
 // instantiation.  Read lattice_wd.hip's header first.
 namespace RNNT_WD_NS {
 
