@@ -127,10 +127,15 @@ static bool takes_ring_kernel(hipStream_t stream, const LatticeArgs& a, int N, i
     const int nA = (a.U + WAVE - 1) / WAVE;
     const bool ring_ok = a.redo && a.queue && !a.offs32 && (nA == 1 || a.mail);
     const int kern = lattice_kernel_override();
-    bool use_wd = ring_ok && (long long)2 * N * nA <= 2ll * device_cus(stream) && a.T >= 640 && nA >= 3;
-    // two column blocks: wl's hand-over through LDS wins on short sweeps, wd's blocks of 16 diagonals (from T >= 1024) on long
-    // ones -- while every workgroup has a CU of its own (launch_lattice has the numbers)
-    if (nA == 2) use_wd = ring_ok && (long long)2 * N * nA <= (long long)device_cus(stream) && a.T >= 1200;
+    // From which sweep length on the column-block kernel wins, by the number of column blocks, measured on the WHOLE loss
+    // entry with each kernel pinned (tools/loss_routes.py, profiles/r06_loss_routes.txt: the ring preparation rides in the
+    // gather's launch there, which the sweeps-alone probe charges to wd as a launch of its own).  With a CU for every
+    // workgroup: two blocks from T >= 900 (wl's LDS hand-over wins below), three from 640, four from 400, five from 320,
+    // six and more always (the alternative there is lattice_ws.hip: -9 ... -17 %); with two workgroups per CU: three and more
+    // from 640 as before, six and more always.
+    const long long wgs = (long long)2 * N * nA, cus = device_cus(stream);
+    const int from_t = nA == 2 ? 900 : nA == 3 ? 640 : nA == 4 ? 400 : nA == 5 ? 320 : 128;
+    bool use_wd = ring_ok && ((wgs <= cus && a.T >= from_t) || (wgs <= 2 * cus && nA >= 3 && a.T >= (nA >= 6 ? 128 : 640)));
     if (nA > ws::MAXA_HOST) use_wd = ring_ok;             // wider than one workgroup sweeps: column blocks or stripes
     if (kern == 1 || kern == 3) use_wd = false;
     if (kern == 2) use_wd = ring_ok;
@@ -167,10 +172,10 @@ hipError_t launch_lattice(hipStream_t stream, const LatticeArgs& a, int N, int l
         // boundary columns through L2) and its single-workgroup form k_lattice_wl (boundary columns through LDS).
         // Which one, measured on MI355X (tools/lattice_routes.py, profiles/r05_lattice_routes.txt; us per alpha+beta launch,
         // ws / wd / wl): two column blocks -- wl: T=700, U=100 61 / 48 / 45, T=400 42 / 35 / 31, N=32, T=250 32 / 30 / 25, N=64,
-        // T=300, U=128 39 / 36 / 30, T=900, U=128 77 / 58 / 56 -- except long sweeps on a chip with a CU per workgroup, where
-        // wd's blocks of 16 diagonals win since the end of round 6 (profiles/r06_two_block_routes.txt: U=128, N=16: T=1024
-        // 85 / 61 / 62, T=1200 (U=100) 94 / 68 / 70, T=1500 116 / 80 / 85, T=2000 148 / 98 / 109, N=8, T=3000 210 / 134 / 157;
-        // N=64, T=1500 116 / 82 / 86; N=128 128 / 121 / 110: wl again): wd from T >= 1200 while 2N * 2 <= CUs; three and more: wd while the chip has
+        // T=300, U=128 39 / 36 / 30 -- except long sweeps on a chip with a CU per workgroup, where wd's blocks of 16 diagonals
+        // win since the end of round 6 (profiles/r06_two_block_routes.txt: U=128, N=16: T=1024 85 / 61 / 62, T=1500 116 / 80 / 85,
+        // T=2000 148 / 98 / 109, N=8, T=3000 210 / 134 / 157; N=64, T=1500 116 / 82 / 86; N=128 128 / 121 / 110: wl again; the
+        // thresholds themselves come from the whole entry: takes_ring_kernel above); three and more: wd while the chip has
         // CUs for its workgroups and the sweep is long enough to recover two extra launches (ring preparation in front, the
         // idle redo kernel behind): N=16, T=1500, U=300 161 / 102 / 128, N=32, T=1000, U=200 100 / 72 / 75; N=32, T=500, U=200
         // 64 / 52 / 51; full chips: N=64, T=1500, U=300 199 / 192 / 189, N=128 307 / 414 / 335.
