@@ -26,6 +26,7 @@
 //   Critical path: (T_n + U_n - 1) + K*(waves-1) dependent lse steps.
 #include <algorithm>
 #include <atomic>
+#include <climits>
 #include <cstdlib>
 #include <type_traits>
 
@@ -131,11 +132,13 @@ static bool takes_ring_kernel(hipStream_t stream, const LatticeArgs& a, int N, i
     // entry with each kernel pinned (tools/loss_routes.py, profiles/r06_loss_routes.txt: the ring preparation rides in the
     // gather's launch there, which the sweeps-alone probe charges to wd as a launch of its own).  With a CU for every
     // workgroup: two blocks from T >= 900 (wl's LDS hand-over wins below), three from 640, four from 400, five from 320,
-    // six and more always (the alternative there is lattice_ws.hip: -9 ... -17 %); with two workgroups per CU: three and more
-    // from 640 as before, six and more always.
+    // six and more always (the alternative there is lattice_ws.hip: -9 ... -17 %); with two workgroups per CU the margins
+    // are 1 - 2 % of the call either way: four blocks from T >= 1400, five from 800, six and more always, two and three never
+    // (N=64, T=1000, U=200 691 / 678 us wd / wl, N=80, T=1000, U=192 735 / 723; N=64, T=1500, U=256 1114 / 1131).
     const long long wgs = (long long)2 * N * nA, cus = device_cus(stream);
     const int from_t = nA == 2 ? 900 : nA == 3 ? 640 : nA == 4 ? 400 : nA == 5 ? 320 : 128;
-    bool use_wd = ring_ok && ((wgs <= cus && a.T >= from_t) || (wgs <= 2 * cus && nA >= 3 && a.T >= (nA >= 6 ? 128 : 640)));
+    const int from_t2 = nA <= 3 ? INT_MAX : nA == 4 ? 1400 : nA == 5 ? 800 : 128;
+    bool use_wd = ring_ok && ((wgs <= cus && a.T >= from_t) || (wgs <= 2 * cus && a.T >= from_t2));
     if (nA > ws::MAXA_HOST) use_wd = ring_ok;             // wider than one workgroup sweeps: column blocks or stripes
     if (kern == 1 || kern == 3) use_wd = false;
     if (kern == 2) use_wd = ring_ok;
