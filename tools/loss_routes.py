@@ -3,7 +3,10 @@
 into the gather's launch as in every real call) timed with each lattice kernel pinned -- what tools/lattice_routes.py's
 sweeps-alone numbers (which pay the preparation as a launch of its own on the wd route) leave open at the margins.
 
-    python tools/loss_routes.py N,T,U[,V] ...          us per call: median over interleaved rounds; auto = launch_lattice's choice
+    python tools/loss_routes.py [--fused] N,T,U[,V] ...     us per call: median over interleaved rounds; auto = launch_lattice's choice
+
+--fused: logits in (log-softmax fused into the gather: the lazy log_softmax's route), whose producer does not carry the ring
+preparation -- k_lattice_wd pays it as a launch of its own there, and launch_lattice's thresholds are the later ones.
 """
 import os
 import statistics
@@ -18,8 +21,13 @@ from warp_rnnt_amd import debug, ops  # noqa: E402
 
 def main():
     dev = torch.device("cuda:0")
-    shapes = [tuple(int(v) for v in a.split(",")) for a in sys.argv[1:]]
-    print("us per loss call (dense in, gathered gradients out): median (min)")
+    args = sys.argv[1:]
+    fused = "--fused" in args
+    if fused:
+        args.remove("--fused")
+    kind = ops.IN_LOGITS_DENSE if fused else ops.IN_LOG_PROBS_DENSE
+    shapes = [tuple(int(v) for v in a.split(",")) for a in args]
+    print(f"us per loss call ({'logits' if fused else 'dense log-probs'} in, gathered gradients out): median (min)")
     for sh in shapes:
         N, T, U = sh[:3]
         V = sh[3] if len(sh) > 3 else 64
@@ -34,7 +42,7 @@ def main():
         for rnd in range(8):
             for k in times:
                 with debug.lattice_kernel(k):
-                    c, _ = ops.loss(lp, ys, xn, yn, ops.IN_LOG_PROBS_DENSE, ops.GRADS_GATHERED)
+                    c, _ = ops.loss(lp, ys, xn, yn, kind, ops.GRADS_GATHERED)
                     ran[k] = debug.last_lattice_kernel()
                     if ref is None:
                         ref = c.clone()
@@ -42,7 +50,7 @@ def main():
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     e0.record()
                     for _ in range(10):
-                        ops.loss(lp, ys, xn, yn, ops.IN_LOG_PROBS_DENSE, ops.GRADS_GATHERED)
+                        ops.loss(lp, ys, xn, yn, kind, ops.GRADS_GATHERED)
                     e1.record()
                     torch.cuda.synchronize()
                     if rnd >= 2:

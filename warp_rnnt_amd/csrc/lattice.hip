@@ -120,7 +120,10 @@ int set_lattice_kernel_override(int k) {
 
 // Will launch_lattice hand this call to the ring kernel (k_lattice_wd with flags, queue and -- beyond one column block --
 // rings)?  The one predicate both launch_lattice and lattice_ring_prep use.
-static bool takes_ring_kernel(hipStream_t stream, const LatticeArgs& a, int N, int loader) {
+// folded: the ring preparation rides in the launch of the kernel that produces this call's pair plane (the dense and the
+// gathered input routes); otherwise it is a launch of its own in front of the sweeps (fused logits, compact layout), ~4 us
+// that move the break-even points.
+static bool takes_ring_kernel(hipStream_t stream, const LatticeArgs& a, int N, int loader, bool folded) {
 #ifdef RNNT_LATTICE_LEGACY
     return false;
 #endif
@@ -136,7 +139,11 @@ static bool takes_ring_kernel(hipStream_t stream, const LatticeArgs& a, int N, i
     // are 1 - 2 % of the call either way: four blocks from T >= 1400, five from 800, six and more always, two and three never
     // (N=64, T=1000, U=200 691 / 678 us wd / wl, N=80, T=1000, U=192 735 / 723; N=64, T=1500, U=256 1114 / 1131).
     const long long wgs = (long long)2 * N * nA, cus = device_cus(stream);
-    const int from_t = nA == 2 ? 900 : nA == 3 ? 640 : nA == 4 ? 400 : nA == 5 ? 320 : 128;
+    // (not folded: the break-even points of the fused route, `tools/loss_routes.py --fused` in the same file -- two blocks tie
+    //  at T=1000 and wd leads by 2.4 % at 1300, three tie up to 900 and wd leads by 1.9 % at 1200, four tie at 500 and wd
+    //  leads by 1.1 % at 700, five: wd by 1.8 % at 400)
+    const int from_t = folded ? (nA == 2 ? 900 : nA == 3 ? 640 : nA == 4 ? 400 : nA == 5 ? 320 : 128)
+                              : (nA == 2 ? 1200 : nA == 3 ? 1100 : nA == 4 ? 640 : nA == 5 ? 400 : 128);
     const int from_t2 = nA <= 3 ? INT_MAX : nA == 4 ? 1400 : nA == 5 ? 800 : 128;
     bool use_wd = ring_ok && ((wgs <= cus && a.T >= from_t) || (wgs <= 2 * cus && a.T >= from_t2));
     if (nA > ws::MAXA_HOST) use_wd = ring_ok;             // wider than one workgroup sweeps: column blocks or stripes
@@ -148,7 +155,7 @@ static bool takes_ring_kernel(hipStream_t stream, const LatticeArgs& a, int N, i
 
 bool lattice_ring_prep(hipStream_t stream, const LatticeArgs& a, int N, int loader, RingPrep* prep) {
     static const bool off = ab_getenv("RNNT_NO_PREP_FOLD") != nullptr;     // A/B knob: k_prepare as a launch of its own
-    if (off || !takes_ring_kernel(stream, a, N, loader)) return false;
+    if (off || !takes_ring_kernel(stream, a, N, loader, true)) return false;
     return wd_ring_prep(stream, a, N, prep);
 }
 
@@ -186,7 +193,7 @@ hipError_t launch_lattice(hipStream_t stream, const LatticeArgs& a, int N, int l
         // fp64 on long lattices; retired in round 6: slower than wd at c4 since the hand-written blocks, and not the
         // reference's numbers.  profiles/HISTORY.md keeps its measurements.)
         const int kern = lattice_kernel_override();      // debug / A-B only: 0 by shape, 1 ws, 2 wd, 3 wl
-        const bool use_wd = takes_ring_kernel(stream, a, N, loader);
+        const bool use_wd = takes_ring_kernel(stream, a, N, loader, a.prepared != 0);
         // One column block per sweep (U <= 64): nothing is handed over, so the distributed kernel needs neither the ring
         // preparation in front nor the redo kernel behind -- a plain launch of its three-wave workgroups (LDS-DMA loader,
         // store-only storer, warm instruction cache), faster than lattice_ws.hip's compute + I/O wave pair at every size
